@@ -1,0 +1,157 @@
+/*
+ * nquant_abi.h -- C ABI of libnquant_hip.so: the MI355X (gfx950) implementation of the reference's
+ * PnnQuantizer / PnnLABQuantizer hot path (mcychan/nQuant.android).
+ *
+ * NQ/ = nQuant.master/src/main/java/com/android/nQuant/ in the reference.
+ * Every entry point names the reference interface it replaces.  Plain pointers and sizes only; "host"
+ * entry points take host memory (what a JNI shim gets from GetPrimitiveArrayCritical on the Java int[]),
+ * "_device" entry points take HIP device pointers (what bench.py / a resident pipeline hands over).
+ *
+ * Pixel format: 32-bit ARGB_8888, non-premultiplied, a = c>>>24, r = (c>>16)&255, g = (c>>8)&255, b = c&255,
+ * row-major, index = x + y*width (NQ/PnnQuantizer.java:413-417, NQ/GilbertCurve.java:126).
+ *
+ * All functions return NQ_OK (0) or a negative nq_status; nq_last_error() gives the text.  A JNI shim maps a
+ * non-zero status to the RuntimeException the reference app raises (app/.../MainActivity.java:205-208).
+ * A handle mirrors ONE reference quantizer object: stateful, not re-entrant (NQ/PnnQuantizer.java:17-33);
+ * distinct handles are independent.  There is no CPU fallback: every compute entry point fails with
+ * NQ_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef NQUANT_ABI_H
+#define NQUANT_ABI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NQ_ABI_VERSION 1
+
+typedef struct nq_handle nq_handle;
+
+enum nq_kind { NQ_KIND_RGB = 0,   /* PnnQuantizer      (NQ/PnnQuantizer.java)    */
+               NQ_KIND_LAB = 1 }; /* PnnLABQuantizer   (NQ/PnnLABQuantizer.java) */
+
+enum nq_mode {
+    /* One error-diffusion chain over the whole image with the reference's bin-keyed first-come nearest cache
+     * and ONE java.util.Random(seed) stream: bit-exact against the sequential oracle.  Runs on one GPU lane
+     * (debug / small images).                                                                              */
+    NQ_MODE_REFERENCE_SEQUENTIAL = 0,
+    /* Production mode: independent gilbert curve + error queue + Random stream per tile, lookups with the
+     * reference's cache-miss semantics; bit-exact against the oracle's tiled restatement.                   */
+    NQ_MODE_PARALLEL_TILED = 1,
+    /* No diffusion: out_index[i] = nearestColorIndex(palette, pixel[i]) evaluated per pixel (cache-miss
+     * semantics): BASELINE.json's "dither off, bit-exact index" check.                                      */
+    NQ_MODE_LOOKUP_ONLY = 2
+};
+
+enum nq_status {
+    NQ_OK = 0,
+    NQ_ERR_INVALID = -1,          /* bad argument */
+    NQ_ERR_HIP = -2,              /* HIP runtime error (text in nq_last_error) */
+    NQ_ERR_UNSUPPORTED = -3,      /* a reference branch this build does not run on the GPU yet */
+    NQ_ERR_REFERENCE_THROWS = -4, /* the Java code would throw here (e.g. setAlphaComponent range) */
+    NQ_ERR_NO_DEVICE = -5
+};
+
+/* Scalars convert() derives and the later stages consume.  Same layout as the
+ * oracle's nqo_params. */
+typedef struct nq_params {
+    int32_t kind;
+    int32_t nMaxColors;
+    int32_t hasSemiTransparency;   /* NQ/PnnQuantizer.java:431 */
+    int32_t transparentPixelIndex; /* m_transparentPixelIndex (:420), -1 = none */
+    int32_t transparentColor;      /* m_transparentColor (:22,:422) */
+    int32_t isNano;                /* NQ/PnnLABQuantizer.java:180 */
+    int32_t texicab;               /* NQ/PnnLABQuantizer.java:219 */
+    int32_t quan_rt;
+    int32_t maxbins;
+    int32_t paletteLength;
+    double PR, PG, PB, PA;         /* NQ/PnnQuantizer.java:24,432-436,176-180 */
+    double ratio;
+    double weight;                 /* signed (negated for semi-transparent images, :396-397) */
+    int64_t distinctColors;        /* LAB: pixelMap.size() after the histogram (0 when not needed) */
+} nq_params;
+
+/* ---- lifetime: replaces `new PnnQuantizer(fname)` / `new PnnLABQuantizer(fname)` (NQ/PnnQuantizer.java:35,
+ *      NQ/PnnLABQuantizer.java:24) and garbage collection.  device = HIP device ordinal. ---- */
+int nq_create(int kind, int device, nq_handle** out);
+void nq_destroy(nq_handle* h);
+const char* nq_last_error(const nq_handle* h);   /* h may be NULL: last error of nq_create on this thread */
+int nq_abi_version(void);
+/* All work of the handle is enqueued on this hipStream_t (NULL = the default stream). */
+int nq_set_stream(nq_handle* h, void* hip_stream);
+/* Tile of the PARALLEL_TILED decomposition (default 16x16); <=0 restores the default. */
+int nq_set_tile(nq_handle* h, int tile_w, int tile_h);
+int nq_get_params(const nq_handle* h, nq_params* out);
+int nq_set_params(nq_handle* h, const nq_params* in);
+
+/* ---- Bitmap convert(int nMaxColors, boolean dither)  (NQ/PnnQuantizer.java:409-456) ----
+ * out_argb  [w*h]  : the pixels of the returned Bitmap (always ARGB)
+ * out_index [w*h]  : palette index chosen per pixel (nullable)
+ * out_palette      : room for max(nMaxColors,2) entries;  *out_K = palette length
+ * The input is never modified (the n<=2 rewrite of :424 is applied internally). */
+int nq_convert(nq_handle* h, const uint32_t* argb, int width, int height, int nMaxColors, int dither,
+               int64_t rng_seed, int mode,
+               uint32_t* out_argb, uint16_t* out_index, uint32_t* out_palette, int32_t* out_K);
+/* same, all pixel buffers in device memory (out_palette/out_K stay host); asynchronous on the handle's stream
+ * except for the small palette-parameter readbacks. */
+int nq_convert_device(nq_handle* h, const uint32_t* d_argb, int width, int height, int nMaxColors, int dither,
+                      int64_t rng_seed, int mode,
+                      uint32_t* d_out_argb, uint16_t* d_out_index, uint32_t* out_palette, int32_t* out_K);
+
+/* ---- Integer[] pnnquan(int[] pixels, int nMaxColors) incl. the alpha pre-scan of convert()
+ *      (NQ/PnnQuantizer.java:410-436,134-267; NQ/PnnLABQuantizer.java:131-327) ---- */
+int nq_pnnquan(nq_handle* h, const uint32_t* argb, int width, int height, int nMaxColors,
+               uint32_t* out_palette, int32_t* out_K);
+int nq_pnnquan_device(nq_handle* h, const uint32_t* d_argb, int width, int height, int nMaxColors,
+                      uint32_t* out_palette, int32_t* out_K);
+
+/* ---- int[] dither(cPixels, palette, width, height, dither) of the quantizer object
+ *      (RGB NQ/PnnQuantizer.java:393-407, LAB NQ/PnnLABQuantizer.java:493-522): GilbertCurve.dither
+ *      (NQ/GilbertCurve.java:367-373) followed, for !dither && K>32, by BlueNoise.dither
+ *      (NQ/BlueNoise.java:207-222).  Uses the handle's params (from nq_pnnquan or nq_set_params). ---- */
+int nq_dither(nq_handle* h, const uint32_t* argb, int width, int height, const uint32_t* palette, int K,
+              int dither, int64_t rng_seed, int mode, uint32_t* out_argb, uint16_t* out_index);
+int nq_dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, const uint32_t* palette, int K,
+                     int dither, int64_t rng_seed, int mode, uint32_t* d_out_argb, uint16_t* d_out_index);
+
+/* ---- Ditherable.nearestColorIndex on a cache miss (NQ/Ditherable.java:3-7;
+ *      RGB NQ/PnnQuantizer.java:269-311, LAB NQ/PnnLABQuantizer.java:330-404): pure per colour. ---- */
+int nq_nearest_index(nq_handle* h, const uint32_t* palette, int K, const uint32_t* colors, int64_t M,
+                     int16_t* out_index);
+/* ---- the closest[4] = {idx1, idx2, (int)err1, (int)err2} tuple of closestColorIndex
+ *      (RGB NQ/PnnQuantizer.java:320-363, LAB NQ/PnnLABQuantizer.java:413-464); {-1,-1,-1,-1} where the
+ *      reference returns through nearestColorIndex first (alpha <= alphaThreshold). ---- */
+int nq_closest_tuple(nq_handle* h, const uint32_t* palette, int K, const uint32_t* colors, int64_t M,
+                     int32_t* out_closest4);
+
+/* ---- split pipeline for an image tiled over several GPUs: each rank scans its band, the
+ *      caller reduces the partial histograms between ranks (RCCL via torch.distributed), every rank then
+ *      builds the same palette and dithers its own band.  Buffers are device memory. ---- */
+/* pass 1 over a band: alpha pre-scan partials.  d_scan3 = int64[3]: {max global index of an alpha==0 pixel or -1,
+ * its colour, count of pixels with 0xF < alpha < 0xE0}; index_offset = global index of the band's first pixel.
+ * Reduce across ranks: [0] max (carry [1] of the winner), [2] sum; then nq_set_scan(). */
+int nq_band_scan_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, int64_t index_offset,
+                        int nMaxColors, int64_t* d_scan3);
+int nq_set_scan(nq_handle* h, int nMaxColors, int64_t transparent_index, uint32_t transparent_color,
+                int64_t semi_count);
+/* pass 2 over a band: partial histogram, NQ_HIST_STRIDE doubles per bin x 65536 bins:
+ * {count, sum0, sum1, sum2, sum3} (RGB: a,r,g,b integer sums; LAB: float32 running sums of alpha,L,A,B of
+ * the band in pixel order, widened). */
+#define NQ_HIST_BINS 65536
+#define NQ_HIST_STRIDE 5
+int nq_band_histogram_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, double* d_hist);
+/* palette from per-band histograms laid out [n_bands][65536][5] (already gathered on this rank); band partials
+ * are added in band order (float32 for LAB, exactly as a sequential pass over band-ordered partial sums). */
+int nq_palette_from_histograms_device(nq_handle* h, const double* d_hists, int n_bands, int nMaxColors,
+                                      uint32_t* out_palette, int32_t* out_K);
+
+/* Wall-clock of the stages of the last nq_convert*_ call on this handle, milliseconds, measured with HIP
+ * events on the handle's stream: {prescan, histogram, nn_init, merge, palette_fill, dither, bluenoise, total}. */
+#define NQ_N_STAGES 8
+int nq_get_stage_ms(const nq_handle* h, float* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NQUANT_ABI_H */

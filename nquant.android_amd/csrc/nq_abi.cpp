@@ -1,0 +1,682 @@
+// nq_abi.cpp -- C ABI of libnquant_hip.so (include/nquant_abi.h): handle, device workspace, and the control plane of
+// the reference's convert() (scalar heuristics, GilbertCurve constructor ladder, curve tables).  All per-pixel and
+// per-bin work is launched on the GPU (nq_kernels.hip); there is no CPU fallback.
+//
+// NQ/ = nQuant.master/src/main/java/com/android/nQuant/ in the reference.
+#include "../../include/nquant_abi.h"
+#include "nq_kernels.h"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace nq;
+
+static thread_local std::string g_create_error;
+
+namespace {
+
+const float kCoeffs[3][3] = {{0.299f, 0.587f, 0.114f}, {-0.14713f, -0.28886f, 0.436f}, {0.615f, -0.51499f, -0.10001f}};
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    ~DevBuf() { if (p) (void) hipFree(p); }
+    hipError_t reserve(size_t count) {
+        if (count <= n) return hipSuccess;
+        if (p) { (void) hipFree(p); p = nullptr; n = 0; }
+        hipError_t e = hipMalloc((void**) &p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+};
+
+// Java narrowing (control-plane use)
+inline int j_d2i(double d) {
+    if (d != d) return 0;
+    if (d >= 2147483647.0) return 2147483647;
+    if (d <= -2147483648.0) return (int) 0x80000000;
+    return (int) d;
+}
+inline signed char j_d2b(double d) { return (signed char) (unsigned char) (j_d2i(d) & 0xFF); }
+inline double sqr(double v) { return v * v; }
+
+// GilbertCurve.initWeights (NQ/GilbertCurve.java:336-354): weights only (the zero boxes are enqueued by the kernel)
+void init_weights(float* weights, int size) {
+    const float weightRatio = (float) std::pow((double) (343.0f + 1.0f), (double) (1.0f / (size - 1.0f)));
+    float weight = 1.0f, sumweight = 0.0f;
+    for (int c = 0; c < size; ++c) {
+        sumweight += (weights[size - c - 1] = weight);
+        weight /= weightRatio;
+    }
+    weight = 0.0f;
+    for (int c = 0; c < size; ++c) weight += (weights[c] /= sumweight);
+    weights[0] += 1.0f - weight;
+}
+
+// GilbertCurve constructor (NQ/GilbertCurve.java:50-112); `weight` is the signed constructor parameter
+GilbertConsts gilbert_consts(int K, double weight, bool hasSaliencies, bool dither) {
+    GilbertConsts g;
+    std::memset(&g, 0, sizeof g);
+    const bool hasAlpha = weight < 0;
+    g.hasAlphaW = hasAlpha; g.hasSaliencies = hasSaliencies; g.dither = dither;
+    g.weightAbs = std::fabs(weight);
+    g.margin = weight < .0025 ? 12 : weight < .004 ? 8 : 6;
+    g.sortedByYDiff = K > 128 && weight >= .02 && (!hasAlpha || weight < .18);
+    float beta = K > 4 ? (float) (.6f - .00625f * K) : 1;
+    if (K > 4) {
+        double boundary = .005 - .0000625 * K;
+        beta = (float) (weight > boundary ? .25 : std::fmin(1.5, beta + K * weight));
+        if (K > 16 && K <= 32 && weight < .003) beta += .075f;
+        else if (weight < .0015 || (K > 32 && K < 256)) beta += .1f;
+        if ((K >= 64 && (weight > .012 && weight < .0125)) || (weight > .025 && weight < .03)) beta += .05f;
+        else if (K > 32 && K < 64 && weight < .015) beta = .55f;
+        else if (K > 16 && K <= 32 && weight <= .005) beta += (float) (.05 + weight * K);
+    }
+    else beta *= .95f;
+    if (K > 64 || (K > 4 && weight > .02)) beta *= .4f;
+    if (K > 64 && weight < .02) beta = .18f;
+    signed char DITHER_MAX = weight < .015 ? ((weight > .0025) ? (signed char) 25 : (signed char) 16) : (signed char) 9;
+    if (weight > .99) { beta = (float) weight; DITHER_MAX = 25; }
+    const double edge = hasAlpha ? 1 : std::exp(weight) - .25;
+    const double deviation = weight > .002 ? -.25 : 1;
+    signed char ditherMax = (hasAlpha || DITHER_MAX > 9) ? j_d2b(sqr(std::sqrt((double) DITHER_MAX) + edge * deviation))
+                                                         : j_d2b(DITHER_MAX * (hasSaliencies ? 2 : 2.718281828459045));
+    const int density = K > 16 ? 3200 : 1500;
+    if (K / weight > 5000 && (weight > .045 || (weight > .01 && K < 64))) ditherMax = j_d2b(sqr(5 + edge));
+    else if (weight < .03 && K / weight < density && K >= 16 && K < 256) ditherMax = j_d2b(sqr(5 + edge));
+    g.thresold = DITHER_MAX > 9 ? -112 : -64;
+    g.beta = beta; g.DITHER_MAX = DITHER_MAX; g.ditherMax = ditherMax;
+    init_weights(g.weights, DITHER_MAX);
+    init_weights(g.w1, 1); init_weights(g.w3, 3); init_weights(g.w7, 7);
+    return g;
+}
+
+// generalized Hilbert ("gilbert") curve, NQ/GilbertCurve.java:282-334 + run() :361-364: entries dx | dy << 16
+inline int sgn(int v) { return (v > 0) - (v < 0); }
+void gilbert_rec(std::vector<uint32_t>& out, int x, int y, int ax, int ay, int bx, int by) {
+    const int w = std::abs(ax + ay), h = std::abs(bx + by);
+    const int dax = sgn(ax), day = sgn(ay), dbx = sgn(bx), dby = sgn(by);
+    if (h == 1) { for (int i = 0; i < w; ++i) { out.push_back((uint32_t) x | ((uint32_t) y << 16)); x += dax; y += day; } return; }
+    if (w == 1) { for (int i = 0; i < h; ++i) { out.push_back((uint32_t) x | ((uint32_t) y << 16)); x += dbx; y += dby; } return; }
+    int ax2 = ax / 2, ay2 = ay / 2, bx2 = bx / 2, by2 = by / 2;
+    const int w2 = std::abs(ax2 + ay2), h2 = std::abs(bx2 + by2);
+    if (2 * w > 3 * h) {
+        if ((w2 % 2) != 0 && w > 2) { ax2 += dax; ay2 += day; }
+        gilbert_rec(out, x, y, ax2, ay2, bx, by);
+        gilbert_rec(out, x + ax2, y + ay2, ax - ax2, ay - ay2, bx, by);
+        return;
+    }
+    if ((h2 % 2) != 0 && h > 2) { bx2 += dbx; by2 += dby; }
+    gilbert_rec(out, x, y, bx2, by2, ax2, ay2);
+    gilbert_rec(out, x + bx2, y + by2, ax, ay, bx - bx2, by - by2);
+    gilbert_rec(out, x + (ax - dax) + (bx2 - dbx), y + (ay - day) + (by2 - dby), -bx2, -by2, -(ax - ax2), -(ay - ay2));
+}
+std::vector<uint32_t> gilbert_path(int w, int h) {
+    std::vector<uint32_t> out;
+    out.reserve((size_t) w * h);
+    if (w <= 0 || h <= 0) return out;
+    if (w >= h) gilbert_rec(out, 0, 0, w, 0, 0, h);
+    else gilbert_rec(out, 0, 0, 0, h, w, 0);
+    return out;
+}
+
+} // namespace
+
+struct nq_handle {
+    int kind = 0, device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    nq_params params;
+    int tile_w = 16, tile_h = 16;
+    float stage_ms[NQ_N_STAGES] = {0};
+    // device workspace
+    DevBuf<int> d_palette, d_in, d_out_argb, d_colors, d_tuple;
+    DevBuf<unsigned short> d_out_index, keys_a, keys_b;
+    DevBuf<short> d_bincache, d_short;
+    DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..5] merge stats
+    DevBuf<int> d_ints;               // [0] maxbins, [1] status
+    DevBuf<int> vals_a, vals_b, heap;
+    DevBuf<unsigned char> sort_tmp;
+    DevBuf<unsigned> seg;             // start[65536], end[65536]
+    DevBuf<double> hist;              // [65536][5]
+    DevBuf<float> binf;               // f[4], cnt, err : 6 x 65536
+    DevBuf<double> bind;              // d[4] : 4 x 65536
+    DevBuf<int> bini;                 // nn, tm, mtm : 3 x 65536
+    std::map<std::pair<int, int>, uint32_t*> paths;   // curve tables on the device, by shape
+    hipEvent_t ev[NQ_N_STAGES + 1] = {nullptr};
+    bool tables_ready = false;
+    ~nq_handle() {
+        for (auto& kv : paths) (void) hipFree(kv.second);
+        for (auto& e : ev) if (e) (void) hipEventDestroy(e);
+    }
+};
+
+#define NQ_FAIL(h, code, ...) do { char _b[512]; std::snprintf(_b, sizeof _b, __VA_ARGS__); (h)->err = _b; return (code); } while (0)
+#define NQ_HIP(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
+    NQ_FAIL(h, NQ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
+
+namespace {
+
+int use_device(nq_handle* h) {
+    NQ_HIP(h, hipSetDevice(h->device));
+    if (!h->tables_ready) {
+        double gamma[256];
+        for (int ch = 0; ch < 256; ++ch) {         // CIELABConvertor.gammaToLinear (NQ/CIELABConvertor.java:71-75)
+            const double c = ch / 255.0;
+            gamma[ch] = c < 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
+        }
+        upload_tables(gamma, std::exp(1.5), std::exp(1.75), h->stream);
+        NQ_HIP(h, hipGetLastError());
+        NQ_HIP(h, h->d_scalars.reserve(8));
+        NQ_HIP(h, h->d_ints.reserve(4));
+        NQ_HIP(h, h->d_bincache.reserve(65536));
+        for (auto& e : h->ev) NQ_HIP(h, hipEventCreate(&e));
+        h->tables_ready = true;
+    }
+    return NQ_OK;
+}
+
+DevParams dev_params(const nq_handle* h, int K) {
+    const nq_params& p = h->params;
+    DevParams d;
+    d.kind = h->kind; d.K = K; d.hasSemi = p.hasSemiTransparency; d.hasAlpha = p.transparentPixelIndex > -1;
+    d.transparentColor = p.transparentColor; d.isNano = p.isNano;
+    d.binKeyed = h->kind == NQ_KIND_LAB ? (p.isNano != 0) : !(p.weight > .015);
+    d.nMaxColors = p.nMaxColors; d.rewriteA0 = p.nMaxColors <= 2 && p.nMaxColors > 0; d.pad = 0;
+    d.PR = p.PR; d.PG = p.PG; d.PB = p.PB; d.PA = p.PA; d.ratio = p.ratio; d.weight = p.weight;
+    return d;
+}
+
+int get_path(nq_handle* h, int w, int hgt, const uint32_t** out) {
+    auto key = std::make_pair(w, hgt);
+    auto it = h->paths.find(key);
+    if (it == h->paths.end()) {
+        std::vector<uint32_t> p = gilbert_path(w, hgt);
+        uint32_t* d = nullptr;
+        NQ_HIP(h, hipMalloc((void**) &d, (p.size() ? p.size() : 1) * sizeof(uint32_t)));
+        hipError_t e = hipMemcpyAsync(d, p.data(), p.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);   // p goes out of scope
+        if (e != hipSuccess) { (void) hipFree(d); NQ_FAIL(h, NQ_ERR_HIP, "curve table upload failed: %s", hipGetErrorString(e)); }
+        it = h->paths.emplace(key, d).first;
+    }
+    *out = it->second;
+    return NQ_OK;
+}
+
+nq::Bins bins_of(nq_handle* h) {
+    nq::Bins B;
+    for (int c = 0; c < 4; ++c) { B.f[c] = h->binf.p + (size_t) c * 65536; B.d[c] = h->bind.p + (size_t) c * 65536; }
+    B.cnt = h->binf.p + (size_t) 4 * 65536; B.err = h->binf.p + (size_t) 5 * 65536;
+    B.nn = h->bini.p; B.tm = h->bini.p + 65536; B.mtm = h->bini.p + 2 * 65536;
+    return B;
+}
+
+int reserve_palette_ws(nq_handle* h, int64_t n) {
+    NQ_HIP(h, h->keys_a.reserve((size_t) n)); NQ_HIP(h, h->keys_b.reserve((size_t) n));
+    NQ_HIP(h, h->vals_a.reserve((size_t) n)); NQ_HIP(h, h->vals_b.reserve((size_t) n));
+    NQ_HIP(h, h->sort_tmp.reserve(sort_temp_bytes(n) + 256));
+    NQ_HIP(h, h->seg.reserve(2 * 65536));
+    NQ_HIP(h, h->hist.reserve((size_t) 65536 * 5));
+    NQ_HIP(h, h->binf.reserve((size_t) 6 * 65536)); NQ_HIP(h, h->bind.reserve((size_t) 4 * 65536));
+    NQ_HIP(h, h->bini.reserve((size_t) 3 * 65536)); NQ_HIP(h, h->heap.reserve(65536 + 2));
+    return NQ_OK;
+}
+
+// the scalar part of convert() after the pre-scan (NQ/PnnQuantizer.java:431-436)
+void apply_scan(nq_handle* h, int nMaxColors, int64_t transparent_index, uint32_t transparent_color, int64_t semi_count) {
+    nq_params& p = h->params;
+    p.kind = h->kind; p.nMaxColors = nMaxColors;
+    p.transparentPixelIndex = transparent_index >= 0 ? (int32_t) transparent_index : -1;
+    p.transparentColor = (int32_t) 0x00FFFFFFu;                       // Color.argb(0,255,255,255) (:22)
+    if (transparent_index >= 0 && nMaxColors > 2) p.transparentColor = (int32_t) transparent_color;   // :421-424
+    p.hasSemiTransparency = semi_count > 0;
+    if (nMaxColors <= 32) p.PR = p.PG = p.PB = p.PA = 1;
+    else { p.PR = kCoeffs[0][0]; p.PG = kCoeffs[0][1]; p.PB = kCoeffs[0][2]; p.PA = .3333; }
+    p.ratio = .5; p.weight = 1; p.isNano = 0; p.texicab = 0; p.quan_rt = 1; p.maxbins = 0; p.paletteLength = 0;
+    p.distinctColors = 0;
+}
+
+void rec(nq_handle* h, int i) { (void) hipEventRecord(h->ev[i], h->stream); }
+
+// pnnquan after the histogram(s) exist on the device (P4..P10)
+int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMaxColors, uint32_t* out_palette, int32_t* out_K) {
+    nq_params& p = h->params;
+    const int kind = h->kind;
+    nq::Bins B = bins_of(h);
+    int* d_maxbins = h->d_ints.p;
+    launch_compact(kind, d_hists, n_bands, B, d_maxbins, h->stream);
+    int maxbins = 0;
+    NQ_HIP(h, hipMemcpyAsync(&maxbins, d_maxbins, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (maxbins <= 0) NQ_FAIL(h, NQ_ERR_INVALID, "empty image");
+    p.maxbins = maxbins;
+    short quan_rt = 1;
+    int fn = 0;
+    bool texicab = false;
+    double proportional = 0;
+    if (kind == NQ_KIND_RGB) {
+        // NQ/PnnQuantizer.java:172-182
+        if (nMaxColors < 16) quan_rt = -1;
+        p.weight = std::fmin(0.9, nMaxColors * 1.0 / maxbins);
+        if (p.weight < .04 && p.PG >= kCoeffs[0][1]) {
+            p.PR = p.PG = p.PB = p.PA = 1;
+            if (nMaxColors >= 64) quan_rt = 0;
+        }
+        if (quan_rt > 0) fn = nMaxColors < 64 ? 1 : 2;
+        else if (quan_rt < 0) fn = 3;
+    } else {
+        // NQ/PnnLABQuantizer.java:175-241
+        proportional = sqr(nMaxColors) / maxbins;
+        if ((p.transparentPixelIndex >= 0 || p.hasSemiTransparency) && nMaxColors < 32) quan_rt = -1;
+        p.weight = std::fmin(0.9, nMaxColors * 1.0 / maxbins);
+        p.isNano = p.weight <= .015;
+        const double weight = p.weight;
+        if ((nMaxColors < 16 && weight < .0075) || weight < .001 || (weight > .0015 && weight < .0022)) quan_rt = 2;
+        if (weight < .04 && p.PG < 1 && p.PG >= kCoeffs[0][1]) {
+            if (nMaxColors >= 64) quan_rt = 0;
+        }
+        if (nMaxColors > 16 && nMaxColors < 64) {
+            double weightB = nMaxColors / 8000.0;
+            if (std::fabs(weightB - weight) < .001) quan_rt = 2;
+        }
+        if (maxbins <= nMaxColors)
+            NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "image with <= nMaxColors occupied bins: the pixelMap.size() <= nMaxColors early "
+                    "return (NQ/PnnLABQuantizer.java:193-206, HashMap key order) is not implemented on the GPU yet");
+        if (quan_rt > 0) fn = quan_rt > 1 ? 4 : (nMaxColors < 64 ? 2 : 1);
+        texicab = proportional > .0225 && !p.hasSemiTransparency;
+        if (p.hasSemiTransparency) p.ratio = .5;
+        else if (quan_rt != 0 && nMaxColors < 64) {
+            if (proportional > .018 && proportional < .022) p.ratio = std::fmin(1.0, proportional + weight * std::exp(3.13));
+            else if (proportional > .1) p.ratio = std::fmin(1.0, 1.0 - weight);
+            else if (proportional > .04) p.ratio = std::fmin(1.0, weight * std::exp(1.56));
+            else if (proportional > .025 && (weight < .002 || weight > .0022)) p.ratio = std::fmin(1.0, proportional + weight * std::exp(3.66));
+            else p.ratio = std::fmin(1.0, proportional + weight * std::exp(1.718));
+        }
+        else if (nMaxColors > 256) p.ratio = std::fmin(1.0, 1 - 1.0 / proportional);
+        else p.ratio = std::fmin(1.0, 1 - weight * .7);
+        if (!p.hasSemiTransparency && quan_rt < 0) p.ratio = std::fmin(1.0, weight * std::exp(3.13));
+    }
+    p.quan_rt = quan_rt; p.texicab = texicab;
+    launch_quanfn(B.cnt, maxbins, fn, h->stream);
+
+    nq::NNParams np;
+    np.kind = kind; np.hasSemi = p.hasSemiTransparency; np.texicab = texicab;
+    np.ratio = p.ratio; np.PR = p.PR; np.PG = p.PG; np.PB = p.PB; np.PA = p.PA;
+    np.pgLessThanCoeff = p.PG < kCoeffs[0][1];
+    rec(h, 2);
+    launch_find_nn_init(np, B, maxbins, h->stream);
+    rec(h, 3);
+    if (kind == NQ_KIND_LAB) {
+        // NQ/PnnLABQuantizer.java:259-264: ratio retuned AFTER the initial pass
+        const double weight = p.weight;
+        if (quan_rt > 0 && nMaxColors < 64 && proportional > .035 && proportional < .1) {
+            const int dir = proportional > .04 ? 1 : -1;
+            const double margin = dir > 0 ? .002 : .0025;
+            const double delta = weight > margin && weight < .003 ? 1.872 : 1.632;
+            p.ratio = std::fmin(1.0, proportional + dir * weight * std::exp(delta));
+            np.ratio = p.ratio;
+        }
+    }
+    const int extbins = maxbins - nMaxColors;
+    launch_merge(np, B, maxbins, extbins, h->heap.p, h->d_scalars.p + 4, h->stream);
+    rec(h, 4);
+    const int plen = extbins > 0 ? nMaxColors : maxbins;
+    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(plen, 2)));
+    int* d_status = h->d_ints.p + 1;
+    launch_palette_fill(kind, B, maxbins, plen, h->d_palette.p, d_status, h->stream);
+    rec(h, 5);
+    int status = 0;
+    NQ_HIP(h, hipMemcpyAsync(out_palette, h->d_palette.p, plen * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    NQ_HIP(h, hipGetLastError());
+    if (status) NQ_FAIL(h, NQ_ERR_REFERENCE_THROWS, "ColorUtils.setAlphaComponent: alpha outside 0..255 (the reference throws IllegalArgumentException)");
+    p.paletteLength = plen;
+    *out_K = plen;
+    return NQ_OK;
+}
+
+int pnnquan_device(nq_handle* h, const uint32_t* d_argb, int width, int height, int nMaxColors, uint32_t* out_palette, int32_t* out_K) {
+    if (!d_argb || width <= 0 || height <= 0 || !out_palette || !out_K) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    if (nMaxColors < 1 || nMaxColors > 32767) NQ_FAIL(h, NQ_ERR_INVALID, "nMaxColors out of range");
+    const int64_t n = (int64_t) width * height;
+    if (n > 2147483647LL) NQ_FAIL(h, NQ_ERR_INVALID, "image larger than a Java int[]");
+    long long* d_scan3 = h->d_scalars.p + 1;
+    rec(h, 0);
+    launch_prescan((const int*) d_argb, n, 0, d_scan3, h->stream);
+    long long scan3[3];
+    NQ_HIP(h, hipMemcpyAsync(scan3, d_scan3, sizeof scan3, hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    apply_scan(h, nMaxColors, scan3[0], (uint32_t) scan3[1], scan3[2]);
+    rec(h, 1);
+    nq_params& p = h->params;
+    if (nMaxColors <= 2) {
+        // NQ/PnnQuantizer.java:441-452
+        p.weight = 1;
+        if (p.transparentPixelIndex >= 0) { out_palette[0] = (uint32_t) p.transparentColor; out_palette[1] = 0xFF000000u; }
+        else { out_palette[0] = 0xFF000000u; out_palette[1] = 0xFFFFFFFFu; }
+        p.paletteLength = nMaxColors; *out_K = nMaxColors;
+        rec(h, 2); rec(h, 3); rec(h, 4); rec(h, 5);
+        return NQ_OK;
+    }
+    int rc = reserve_palette_ws(h, n);
+    if (rc) return rc;
+    nq::HistParams hp;
+    hp.hasSemi = p.hasSemiTransparency; hp.hasTransp = nMaxColors < 64 || p.transparentPixelIndex >= 0;
+    hp.transparentColor = p.transparentColor; hp.rewriteTransparent = 0;
+    nq::SortWorkspace ws;
+    ws.keys_a = h->keys_a.p; ws.keys_b = h->keys_b.p; ws.vals_a = h->vals_a.p; ws.vals_b = h->vals_b.p;
+    ws.tmp = h->sort_tmp.p; ws.tmp_bytes = h->sort_tmp.n; ws.seg_start = h->seg.p; ws.seg_end = h->seg.p + 65536;
+    launch_histogram(h->kind, (const int*) d_argb, n, hp, ws, h->hist.p, h->stream);
+    return palette_from_hist(h, h->hist.p, 1, nMaxColors, out_palette, out_K);
+}
+
+int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, const uint32_t* palette, int K, int dither,
+                  int64_t seed, int mode, uint32_t* d_out_argb, uint16_t* d_out_index) {
+    if (!d_argb || width <= 0 || height <= 0 || !palette || K < 1 || !d_out_argb) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    if (width > 65535 || height > 65535) NQ_FAIL(h, NQ_ERR_INVALID, "image side > 65535");
+    if (K > 8192) NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "palettes above 8192 entries do not fit the LDS staging");
+    const int64_t n = (int64_t) width * height;
+    nq_params& p = h->params;
+    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(K, 2)));
+    NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (!d_out_index) { NQ_HIP(h, h->d_out_index.reserve((size_t) n)); d_out_index = h->d_out_index.p; }
+
+    if (mode == NQ_MODE_LOOKUP_ONLY) {
+        DevParams P = dev_params(h, K);
+        launch_lookup_only(P, h->d_palette.p, (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
+        NQ_HIP(h, hipGetLastError());
+        return NQ_OK;
+    }
+    if (mode != NQ_MODE_PARALLEL_TILED && mode != NQ_MODE_REFERENCE_SEQUENTIAL) NQ_FAIL(h, NQ_ERR_INVALID, "unknown mode %d", mode);
+    const bool sequential = mode == NQ_MODE_REFERENCE_SEQUENTIAL;
+
+    // dither(): RGB NQ/PnnQuantizer.java:393-407, LAB NQ/PnnLABQuantizer.java:493-522
+    if (p.hasSemiTransparency) p.weight *= -1;
+    bool hasSal = false, salSubst = false;
+    if (h->kind == NQ_KIND_LAB) {
+        if (p.nMaxColors > 2 && p.nMaxColors < 128) { hasSal = true; salSubst = true; }       // pnnquan :135,:155-156
+        else if (dither && (K <= 256 || p.weight > .99)) { hasSal = true; }                   // :499-508
+    }
+    const bool post = !dither && K > 32;
+    float blueWeight = 1.0f;
+    if (post && h->kind == NQ_KIND_LAB) {
+        if (sequential)
+            NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "REFERENCE_SEQUENTIAL + LAB + dither=false + K>32 needs pixelMap.size() after the gilbert "
+                    "pass (NQ/PnnLABQuantizer.java:512); not tracked on the GPU");
+        if (p.distinctColors <= 0)
+            NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "params.distinctColors is required for the LAB BlueNoise weight (NQ/PnnLABQuantizer.java:512)");
+        const double delta = sqr(K) / (double) p.distinctColors;
+        blueWeight = delta > 0.023 ? 1.0f : (float) (37.013 * delta + 0.906);
+    }
+    DevParams P = dev_params(h, K);
+    GilbertConsts G = gilbert_consts(K, p.weight, hasSal, dither != 0);
+    G.salSubst = salSubst;
+
+    TileGeom T;
+    std::memset(&T, 0, sizeof T);
+    T.width = width; T.height = height;
+    if (sequential) { T.tile_w = width; T.tile_h = height; }
+    else { T.tile_w = std::min(h->tile_w, width); T.tile_h = std::min(h->tile_h, height); }
+    T.tiles_x = (width + T.tile_w - 1) / T.tile_w; T.tiles_y = (height + T.tile_h - 1) / T.tile_h;
+    const int rw = width - (T.tiles_x - 1) * T.tile_w, rh = height - (T.tiles_y - 1) * T.tile_h;
+    const int sw[4] = {T.tile_w, rw, T.tile_w, rw}, shh[4] = {T.tile_h, T.tile_h, rh, rh};
+    for (int s = 0; s < 4; ++s) {
+        int rc = get_path(h, sw[s], shh[s], &T.path[s]);
+        if (rc) return rc;
+        T.path_len[s] = sw[s] * shh[s]; T.shape_w[s] = sw[s]; T.shape_h[s] = shh[s];
+    }
+    if (sequential) NQ_HIP(h, hipMemsetAsync(h->d_bincache.p, 0xFF, 65536 * sizeof(short), h->stream));
+    rec(h, 5);
+    launch_gilbert(P, G, T, (const int*) d_argb, h->d_palette.p, h->d_bincache.p, (long long) seed, sequential ? 1 : 0,
+                   h->d_scalars.p, d_out_index, post ? nullptr : (int*) d_out_argb, h->stream);
+    rec(h, 6);
+    if (post)
+        launch_bluenoise(P, h->d_palette.p, (const int*) d_argb, width, height, blueWeight, (long long) seed, sequential ? 1 : 0,
+                         h->d_bincache.p, h->d_scalars.p, d_out_index, (int*) d_out_argb, h->stream);
+    rec(h, 7);
+    NQ_HIP(h, hipGetLastError());
+    return NQ_OK;
+}
+
+void finish_timing(nq_handle* h) {
+    // {prescan, histogram, nn_init, merge, palette_fill, dither, bluenoise, total}
+    for (int i = 0; i < 7; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = 0;
+        h->stage_ms[i] = ms;
+    }
+    float tot = 0;
+    if (hipEventElapsedTime(&tot, h->ev[0], h->ev[7]) != hipSuccess) tot = 0;
+    h->stage_ms[7] = tot;
+}
+
+} // namespace
+
+extern "C" {
+
+int nq_abi_version(void) { return NQ_ABI_VERSION; }
+
+int nq_create(int kind, int device, nq_handle** out) {
+    if (!out) { g_create_error = "out is NULL"; return NQ_ERR_INVALID; }
+    *out = nullptr;
+    if (kind != NQ_KIND_RGB && kind != NQ_KIND_LAB) { g_create_error = "unknown kind"; return NQ_ERR_INVALID; }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = "no HIP device available (libnquant_hip has no CPU fallback)";
+        return NQ_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) { g_create_error = "device ordinal out of range"; return NQ_ERR_INVALID; }
+    nq_handle* h = new nq_handle();
+    h->kind = kind; h->device = device;
+    std::memset(&h->params, 0, sizeof h->params);
+    h->params.kind = kind; h->params.transparentPixelIndex = -1; h->params.transparentColor = (int32_t) 0x00FFFFFFu;
+    h->params.PR = 0.299; h->params.PG = 0.587; h->params.PB = 0.114; h->params.PA = .3333; h->params.ratio = .5; h->params.weight = 1;
+    int rc = use_device(h);
+    if (rc) { g_create_error = h->err; delete h; return rc; }
+    *out = h;
+    return NQ_OK;
+}
+
+void nq_destroy(nq_handle* h) {
+    if (!h) return;
+    (void) hipSetDevice(h->device);
+    (void) hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+const char* nq_last_error(const nq_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int nq_set_stream(nq_handle* h, void* hip_stream) {
+    if (!h) return NQ_ERR_INVALID;
+    h->stream = (hipStream_t) hip_stream;
+    return NQ_OK;
+}
+int nq_set_tile(nq_handle* h, int tile_w, int tile_h) {
+    if (!h) return NQ_ERR_INVALID;
+    if (tile_w <= 0 || tile_h <= 0) { tile_w = 16; tile_h = 16; }
+    h->tile_w = tile_w; h->tile_h = tile_h;
+    return NQ_OK;
+}
+int nq_get_params(const nq_handle* h, nq_params* out) {
+    if (!h || !out) return NQ_ERR_INVALID;
+    *out = h->params;
+    return NQ_OK;
+}
+int nq_set_params(nq_handle* h, const nq_params* in) {
+    if (!h || !in) return NQ_ERR_INVALID;
+    h->params = *in; h->params.kind = h->kind;
+    return NQ_OK;
+}
+int nq_get_stage_ms(const nq_handle* h, float* out8) {
+    if (!h || !out8) return NQ_ERR_INVALID;
+    std::memcpy(out8, h->stage_ms, sizeof h->stage_ms);
+    return NQ_OK;
+}
+
+int nq_pnnquan_device(nq_handle* h, const uint32_t* d_argb, int width, int height, int nMaxColors,
+                      uint32_t* out_palette, int32_t* out_K) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    return pnnquan_device(h, d_argb, width, height, nMaxColors, out_palette, out_K);
+}
+
+int nq_pnnquan(nq_handle* h, const uint32_t* argb, int width, int height, int nMaxColors, uint32_t* out_palette, int32_t* out_K) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!argb || width <= 0 || height <= 0) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    const size_t n = (size_t) width * height;
+    NQ_HIP(h, h->d_in.reserve(n));
+    NQ_HIP(h, hipMemcpyAsync(h->d_in.p, argb, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return pnnquan_device(h, (const uint32_t*) h->d_in.p, width, height, nMaxColors, out_palette, out_K);
+}
+
+int nq_dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, const uint32_t* palette, int K,
+                     int dither, int64_t rng_seed, int mode, uint32_t* d_out_argb, uint16_t* d_out_index) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    return dither_device(h, d_argb, width, height, palette, K, dither, rng_seed, mode, d_out_argb, d_out_index);
+}
+
+int nq_dither(nq_handle* h, const uint32_t* argb, int width, int height, const uint32_t* palette, int K,
+              int dither, int64_t rng_seed, int mode, uint32_t* out_argb, uint16_t* out_index) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!argb || !out_argb || width <= 0 || height <= 0) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    const size_t n = (size_t) width * height;
+    NQ_HIP(h, h->d_in.reserve(n)); NQ_HIP(h, h->d_out_argb.reserve(n)); NQ_HIP(h, h->d_out_index.reserve(n));
+    NQ_HIP(h, hipMemcpyAsync(h->d_in.p, argb, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    rc = dither_device(h, (const uint32_t*) h->d_in.p, width, height, palette, K, dither, rng_seed, mode,
+                       (uint32_t*) h->d_out_argb.p, h->d_out_index.p);
+    if (rc) return rc;
+    NQ_HIP(h, hipMemcpyAsync(out_argb, h->d_out_argb.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (out_index) NQ_HIP(h, hipMemcpyAsync(out_index, h->d_out_index.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    return NQ_OK;
+}
+
+int nq_convert_device(nq_handle* h, const uint32_t* d_argb, int width, int height, int nMaxColors, int dither,
+                      int64_t rng_seed, int mode, uint32_t* d_out_argb, uint16_t* d_out_index,
+                      uint32_t* out_palette, int32_t* out_K) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    rc = pnnquan_device(h, d_argb, width, height, nMaxColors, out_palette, out_K);
+    if (rc) return rc;
+    rc = dither_device(h, d_argb, width, height, out_palette, *out_K, dither, rng_seed, mode, d_out_argb, d_out_index);
+    if (rc) return rc;
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    finish_timing(h);
+    return NQ_OK;
+}
+
+int nq_convert(nq_handle* h, const uint32_t* argb, int width, int height, int nMaxColors, int dither,
+               int64_t rng_seed, int mode, uint32_t* out_argb, uint16_t* out_index, uint32_t* out_palette, int32_t* out_K) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!argb || !out_argb || width <= 0 || height <= 0) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    const size_t n = (size_t) width * height;
+    NQ_HIP(h, h->d_in.reserve(n)); NQ_HIP(h, h->d_out_argb.reserve(n)); NQ_HIP(h, h->d_out_index.reserve(n));
+    NQ_HIP(h, hipMemcpyAsync(h->d_in.p, argb, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    rc = nq_convert_device(h, (const uint32_t*) h->d_in.p, width, height, nMaxColors, dither, rng_seed, mode,
+                           (uint32_t*) h->d_out_argb.p, h->d_out_index.p, out_palette, out_K);
+    if (rc) return rc;
+    NQ_HIP(h, hipMemcpyAsync(out_argb, h->d_out_argb.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (out_index) NQ_HIP(h, hipMemcpyAsync(out_index, h->d_out_index.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    return NQ_OK;
+}
+
+int nq_nearest_index(nq_handle* h, const uint32_t* palette, int K, const uint32_t* colors, int64_t M, int16_t* out_index) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!palette || K < 1 || K > 8192 || !colors || M < 0 || !out_index) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    if (M == 0) return NQ_OK;
+    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(K, 2))); NQ_HIP(h, h->d_colors.reserve((size_t) M)); NQ_HIP(h, h->d_short.reserve((size_t) M));
+    NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    NQ_HIP(h, hipMemcpyAsync(h->d_colors.p, colors, (size_t) M * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    DevParams P = dev_params(h, K);
+    launch_nearest_index(P, h->d_palette.p, h->d_colors.p, M, h->d_short.p, h->stream);
+    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, hipMemcpyAsync(out_index, h->d_short.p, (size_t) M * sizeof(short), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    return NQ_OK;
+}
+
+int nq_closest_tuple(nq_handle* h, const uint32_t* palette, int K, const uint32_t* colors, int64_t M, int32_t* out_closest4) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!palette || K < 1 || K > 8192 || !colors || M < 0 || !out_closest4) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    if (M == 0) return NQ_OK;
+    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(K, 2))); NQ_HIP(h, h->d_colors.reserve((size_t) M)); NQ_HIP(h, h->d_tuple.reserve((size_t) 4 * M));
+    NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    NQ_HIP(h, hipMemcpyAsync(h->d_colors.p, colors, (size_t) M * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    DevParams P = dev_params(h, K);
+    launch_closest_tuple(P, h->d_palette.p, h->d_colors.p, M, h->d_tuple.p, h->stream);
+    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, hipMemcpyAsync(out_closest4, h->d_tuple.p, (size_t) 4 * M * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    return NQ_OK;
+}
+
+int nq_band_scan_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, int64_t index_offset, int nMaxColors, int64_t* d_scan3) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!d_argb || n_pixels <= 0 || !d_scan3) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    (void) nMaxColors;
+    launch_prescan((const int*) d_argb, n_pixels, index_offset, (long long*) d_scan3, h->stream);
+    NQ_HIP(h, hipGetLastError());
+    return NQ_OK;
+}
+
+int nq_set_scan(nq_handle* h, int nMaxColors, int64_t transparent_index, uint32_t transparent_color, int64_t semi_count) {
+    if (!h) return NQ_ERR_INVALID;
+    apply_scan(h, nMaxColors, transparent_index, transparent_color, semi_count);
+    return NQ_OK;
+}
+
+int nq_band_histogram_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, double* d_hist) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!d_argb || n_pixels <= 0 || !d_hist) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    rc = reserve_palette_ws(h, n_pixels);
+    if (rc) return rc;
+    const nq_params& p = h->params;
+    nq::HistParams hp;
+    hp.hasSemi = p.hasSemiTransparency; hp.hasTransp = p.nMaxColors < 64 || p.transparentPixelIndex >= 0;
+    hp.transparentColor = p.transparentColor; hp.rewriteTransparent = 0;
+    nq::SortWorkspace ws;
+    ws.keys_a = h->keys_a.p; ws.keys_b = h->keys_b.p; ws.vals_a = h->vals_a.p; ws.vals_b = h->vals_b.p;
+    ws.tmp = h->sort_tmp.p; ws.tmp_bytes = h->sort_tmp.n; ws.seg_start = h->seg.p; ws.seg_end = h->seg.p + 65536;
+    launch_histogram(h->kind, (const int*) d_argb, n_pixels, hp, ws, d_hist, h->stream);
+    NQ_HIP(h, hipGetLastError());
+    return NQ_OK;
+}
+
+int nq_palette_from_histograms_device(nq_handle* h, const double* d_hists, int n_bands, int nMaxColors,
+                                      uint32_t* out_palette, int32_t* out_K) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!d_hists || n_bands < 1 || !out_palette || !out_K || nMaxColors < 3) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    rc = reserve_palette_ws(h, 1);
+    if (rc) return rc;
+    return palette_from_hist(h, d_hists, n_bands, nMaxColors, out_palette, out_K);
+}
+
+} // extern "C"

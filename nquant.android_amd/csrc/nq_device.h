@@ -1,0 +1,523 @@
+// nq_device.h -- device-side building blocks shared by every gfx950 kernel of libnquant_hip.so.
+//
+// Everything here mirrors the arithmetic of the reference (NQ/ = nQuant.master/src/main/java/com/android/nQuant/)
+// type for type: Java float stays f32, Java double stays f64, no fused multiply-add (the whole library is
+// compiled with -ffp-contract=off), Java (int) narrowing made explicit.  Transcendentals come from the ROCm
+// device library (OCML); tables that only depend on an 8-bit channel are computed once on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nq_kernels.h"
+
+namespace nq {
+
+// ------------------------------------------------------------------------------------------------
+// constants shared by all kernels of this translation unit
+// ------------------------------------------------------------------------------------------------
+struct ConstTables {
+    double gamma[256];     // CIELABConvertor.gammaToLinear(ch) == ColorUtils sRGB companding (NQ/CIELABConvertor.java:71-75)
+    double exp1_5;         // Math.exp(1.5)   (NQ/PnnLABQuantizer.java:348)
+    double exp1_75;        // Math.exp(1.75)  (NQ/PnnLABQuantizer.java:62)
+    int8_t blue[4096];     // TELL_BLUE_NOISE (NQ/BlueNoise.java:13-178), data
+};
+extern __constant__ ConstTables g_tab;   // defined in nq_kernels.hip (single translation unit)
+
+// struct DevParams: nq_kernels.h
+
+#define NQ_PI 3.141592653589793
+#define NQ_E 2.718281828459045
+
+// ---- Java numeric narrowing -------------------------------------------------------------------
+__device__ __forceinline__ int j_d2i(double d) {
+    if (d != d) return 0;
+    if (d >= 2147483647.0) return 2147483647;
+    if (d <= -2147483648.0) return (int) 0x80000000;
+    return (int) d;
+}
+__device__ __forceinline__ long long j_round(double a) {      // Math.round(double)
+    if (a != a) return 0;
+    if (fabs(a) >= 4503599627370496.0) return (long long) a;
+    double f = floor(a);
+    return (long long) f + ((a - f) >= 0.5 ? 1 : 0);
+}
+__device__ __forceinline__ double sqr(double v) { return v * v; }
+
+// ---- android.graphics.Color ---------------------------------------------------------------------
+__device__ __forceinline__ int c_alpha(int c) { return (int) (((unsigned) c) >> 24); }
+__device__ __forceinline__ int c_red(int c) { return (c >> 16) & 0xFF; }
+__device__ __forceinline__ int c_green(int c) { return (c >> 8) & 0xFF; }
+__device__ __forceinline__ int c_blue(int c) { return c & 0xFF; }
+__device__ __forceinline__ int c_argb(int a, int r, int g, int b) {
+    return (int) (((unsigned) a << 24) | ((unsigned) r << 16) | ((unsigned) g << 8) | (unsigned) b);
+}
+
+// NQ/BitmapUtilities.java:8-15
+__device__ __forceinline__ int getColorIndex(int c, bool hasSemiTransparency, bool hasTransparency) {
+    if (hasSemiTransparency)
+        return (c_alpha(c) & 0xF0) << 8 | (c_red(c) & 0xF0) << 4 | (c_green(c) & 0xF0) | (c_blue(c) >> 4);
+    if (hasTransparency)
+        return (c_alpha(c) & 0x80) << 8 | (c_red(c) & 0xF8) << 7 | (c_green(c) & 0xF8) << 2 | (c_blue(c) >> 3);
+    return (c_red(c) & 0xF8) << 8 | (c_green(c) & 0xFC) << 3 | (c_blue(c) >> 3);
+}
+
+// ---- CIELABConvertor ----------------------------------------------------------------------------
+struct Lab { float alpha, A, B, L; };
+
+// RGB2LAB: NQ/CIELABConvertor.java:58-69 over androidx ColorUtils.colorToLAB (published algorithm)
+__device__ __forceinline__ double pivot_xyz(double c) { return c > 0.008856 ? pow(c, 1 / 3.0) : (903.3 * c + 16) / 116; }
+__device__ __forceinline__ void rgb_to_xyz(int c1, double& X, double& Y, double& Z) {
+    double sr = g_tab.gamma[c_red(c1)], sg = g_tab.gamma[c_green(c1)], sb = g_tab.gamma[c_blue(c1)];
+    X = 100 * (sr * 0.4124 + sg * 0.3576 + sb * 0.1805);
+    Y = 100 * (sr * 0.2126 + sg * 0.7152 + sb * 0.0722);
+    Z = 100 * (sr * 0.0193 + sg * 0.1192 + sb * 0.9505);
+}
+__device__ __forceinline__ Lab RGB2LAB(int c1) {
+    double X, Y, Z;
+    rgb_to_xyz(c1, X, Y, Z);
+    double x = pivot_xyz(X / 95.047), y = pivot_xyz(Y / 100.0), z = pivot_xyz(Z / 108.883);
+    Lab lab;
+    lab.alpha = (float) c_alpha(c1);
+    lab.L = (float) fmax(0.0, 116 * y - 16);
+    lab.A = (float) (500 * (x - y));
+    lab.B = (float) (200 * (y - z));
+    return lab;
+}
+// L channel only (the saliency map needs nothing else): same arithmetic as RGB2LAB().L
+__device__ __forceinline__ float RGB2L(int c1) {
+    double sr = g_tab.gamma[c_red(c1)], sg = g_tab.gamma[c_green(c1)], sb = g_tab.gamma[c_blue(c1)];
+    double Y = 100 * (sr * 0.2126 + sg * 0.7152 + sb * 0.0722);
+    double y = pivot_xyz(Y / 100.0);
+    return (float) fmax(0.0, 116 * y - 16);
+}
+// saliency of one pixel: NQ/PnnLABQuantizer.java:156 / :506
+__device__ __forceinline__ float saliency_of(int c) {
+    const float saliencyBase = .1f;
+    float L = RGB2L(c), alpha = (float) c_alpha(c);
+    return saliencyBase + (1 - saliencyBase) * L / 100.0f * alpha / 255.0f;
+}
+
+// LAB2RGB: NQ/CIELABConvertor.java:77-80 over ColorUtils.LABToColor; *ok=false where setAlphaComponent throws
+__device__ __forceinline__ int LAB2RGB(Lab lab, bool* ok) {
+    double l = lab.L, a = lab.A, b = lab.B;
+    double fy = (l + 16) / 116, fx = a / 500 + fy, fz = fy - b / 200;
+    double tmp = pow(fx, 3.0);
+    double xr = tmp > 0.008856 ? tmp : (116 * fx - 16) / 903.3;
+    double yr = l > 903.3 * 0.008856 ? pow(fy, 3.0) : l / 903.3;
+    tmp = pow(fz, 3.0);
+    double zr = tmp > 0.008856 ? tmp : (116 * fz - 16) / 903.3;
+    double x = xr * 95.047, y = yr * 100.0, z = zr * 108.883;
+    double r = (x * 3.2406 + y * -1.5372 + z * -0.4986) / 100;
+    double g = (x * -0.9689 + y * 1.8758 + z * 0.0415) / 100;
+    double bb = (x * 0.0557 + y * -0.2040 + z * 1.0570) / 100;
+    r = r > 0.0031308 ? 1.055 * pow(r, 1 / 2.4) - 0.055 : 12.92 * r;
+    g = g > 0.0031308 ? 1.055 * pow(g, 1 / 2.4) - 0.055 : 12.92 * g;
+    bb = bb > 0.0031308 ? 1.055 * pow(bb, 1 / 2.4) - 0.055 : 12.92 * bb;
+    long long ri = j_round(r * 255), gi = j_round(g * 255), bi = j_round(bb * 255);
+    int R = ri < 0 ? 0 : ri > 255 ? 255 : (int) ri;
+    int G = gi < 0 ? 0 : gi > 255 ? 255 : (int) gi;
+    int B = bi < 0 ? 0 : bi > 255 ? 255 : (int) bi;
+    int alpha = j_d2i((double) lab.alpha);
+    *ok = !(alpha < 0 || alpha > 255);
+    return (int) ((((unsigned) alpha) << 24) | ((unsigned) R << 16) | ((unsigned) G << 8) | (unsigned) B);
+}
+
+// :86-89
+__device__ __forceinline__ float deg2Rad(double deg) { return (float) (deg * (NQ_PI / 180.0)); }
+
+// :91-98
+__device__ __forceinline__ float L_prime_div_k_L_S_L(const Lab& lab1, const Lab& lab2) {
+    const float k_L = 1.0f;
+    float deltaLPrime = lab2.L - lab1.L;
+    float barLPrime = (lab1.L + lab2.L) / 2.0f;
+    double p = sqr((double) (barLPrime - 50.0f));
+    float S_L = (float) (1 + (((double) 0.015f * p) / sqrt(20 + p)));
+    return deltaLPrime / (k_L * S_L);
+}
+// :100-118
+__device__ __forceinline__ float C_prime_div_k_L_S_L(const Lab& lab1, const Lab& lab2, double& a1Prime, double& a2Prime,
+                                                     double& CPrime1, double& CPrime2) {
+    const float k_C = 1.0f;
+    const float pow25To7 = 6103515625.0f;
+    float C1 = (float) sqrt((double) ((lab1.A * lab1.A) + (lab1.B * lab1.B)));
+    float C2 = (float) sqrt((double) ((lab2.A * lab2.A) + (lab2.B * lab2.B)));
+    float barC = (C1 + C2) / 2.0f;
+    double barC7 = pow((double) barC, 7.0);
+    float G = (float) ((double) 0.5f * (1 - sqrt(barC7 / (barC7 + (double) pow25To7))));
+    a1Prime = (1.0 + G) * lab1.A;
+    a2Prime = (1.0 + G) * lab2.A;
+    CPrime1 = sqrt((a1Prime * a1Prime) + (double) (lab1.B * lab1.B));
+    CPrime2 = sqrt((a2Prime * a2Prime) + (double) (lab2.B * lab2.B));
+    float deltaCPrime = (float) CPrime2 - (float) CPrime1;
+    float barCPrime = ((float) CPrime1 + (float) CPrime2) / 2.0f;
+    float S_C = 1 + (0.045f * barCPrime);
+    return deltaCPrime / (k_C * S_C);
+}
+// :120-185
+__device__ __forceinline__ float H_prime_div_k_L_S_L(const Lab& lab1, const Lab& lab2, double a1Prime, double a2Prime,
+                                                     double CPrime1, double CPrime2, double& barCPrime, double& barhPrime) {
+    const float k_H = 1.0f;
+    const float deg360InRad = deg2Rad(360.0);
+    const float deg180InRad = deg2Rad(180.0);
+    double CPrimeProduct = CPrime1 * CPrime2;
+    double hPrime1;
+    if ((double) lab1.B == 0.0 && a1Prime == 0.0) hPrime1 = 0.0;
+    else {
+        hPrime1 = atan2((double) lab1.B, a1Prime);
+        if (hPrime1 < 0) hPrime1 += deg360InRad;
+    }
+    double hPrime2;
+    if ((double) lab2.B == 0.0 && a2Prime == 0.0) hPrime2 = 0.0;
+    else {
+        hPrime2 = atan2((double) lab2.B, a2Prime);
+        if (hPrime2 < 0) hPrime2 += deg360InRad;
+    }
+    double deltahPrime;
+    if (CPrimeProduct == 0.0) deltahPrime = 0;
+    else {
+        deltahPrime = hPrime2 - hPrime1;
+        if (deltahPrime < -deg180InRad) deltahPrime += deg360InRad;
+        else if (deltahPrime > deg180InRad) deltahPrime -= deg360InRad;
+    }
+    double deltaHPrime = 2.0 * sqrt(CPrimeProduct) * sin(deltahPrime / 2.0);
+    double hPrimeSum = hPrime1 + hPrime2;
+    if ((CPrime1 * CPrime2) == 0.0) barhPrime = hPrimeSum;
+    else {
+        if (fabs(hPrime1 - hPrime2) <= deg180InRad) barhPrime = hPrimeSum / 2.0;
+        else {
+            if (hPrimeSum < deg360InRad) barhPrime = (hPrimeSum + deg360InRad) / 2.0;
+            else barhPrime = (hPrimeSum - deg360InRad) / 2.0;
+        }
+    }
+    barCPrime = (CPrime1 + CPrime2) / 2.0;
+    double bh = barhPrime;
+    double T = 1.0 - (0.17 * cos(bh - deg2Rad(30.0))) + (0.24 * cos(2.0 * bh)) +
+               (0.32 * cos((3.0 * bh) + deg2Rad(6.0))) - (0.20 * cos((4.0 * bh) - deg2Rad(63.0)));
+    double S_H = 1 + ((double) 0.015f * barCPrime * T);
+    return (float) (deltaHPrime / (k_H * S_H));
+}
+// :187-194
+__device__ __forceinline__ float R_T(double barCPrime, double barhPrime, float C_prime_div, float H_prime_div) {
+    const double pow25To7 = 6103515625.0;
+    double deltaTheta = deg2Rad(30.0) * exp(-sqr((barhPrime - deg2Rad(275.0)) / deg2Rad(25.0)));
+    double bc7 = pow(barCPrime, 7.0);
+    double R_C = 2.0 * sqrt(bc7 / (bc7 + pow25To7));
+    double rt = (-sin(2.0 * deltaTheta)) * R_C;
+    return (float) (rt * C_prime_div * H_prime_div);
+}
+
+// :215-227 / :229-238
+__device__ __forceinline__ double color2Y(int c) {
+    double sr = g_tab.gamma[c_red(c)], sg = g_tab.gamma[c_green(c)], sb = g_tab.gamma[c_blue(c)];
+    return sr * 0.2126 + sg * 0.7152 + sb * 0.0722;
+}
+__device__ __forceinline__ double Y_Diff(int c1, int c2) {
+    double y = color2Y(c1), y2 = color2Y(c2);
+    return fabs(y2 - y) * 100;
+}
+__device__ __forceinline__ double color2U(int c) { return -0.09991 * c_red(c) - 0.33609 * c_green(c) + 0.436 * c_blue(c); }
+__device__ __forceinline__ double U_Diff(int c1, int c2) { return fabs(color2U(c2) - color2U(c1)); }
+
+// NQ/BlueNoise.java:180-197
+__device__ __forceinline__ int blue_diffuse(int pixel, int qPixel, float weight, float strength, int x, int y) {
+    int r_pix = c_red(pixel), g_pix = c_green(pixel), b_pix = c_blue(pixel), a_pix = c_alpha(pixel);
+    float adj = (g_tab.blue[(x & 63) | (y & 63) << 6] + 0.5f) / 127.5f;
+    adj += (((x + y) & 1) - 0.5f) * strength / 8.0f;
+    adj *= weight;
+    r_pix = j_d2i(fmin(255.0, fmax((double) (r_pix + (adj * (r_pix - c_red(qPixel)))), 0.0)));
+    g_pix = j_d2i(fmin(255.0, fmax((double) (g_pix + (adj * (g_pix - c_green(qPixel)))), 0.0)));
+    b_pix = j_d2i(fmin(255.0, fmax((double) (b_pix + (adj * (b_pix - c_blue(qPixel)))), 0.0)));
+    a_pix = j_d2i(fmin(255.0, fmax((double) (a_pix + (adj * (a_pix - c_alpha(qPixel)))), 0.0)));
+    return c_argb(a_pix, r_pix, g_pix, b_pix);
+}
+
+// ---- java.util.Random ---------------------------------------------------------------------------
+#define NQ_JR_MULT 0x5DEECE66DLL
+#define NQ_JR_MASK ((1LL << 48) - 1)
+__host__ __device__ __forceinline__ long long jr_seed(long long seed) { return (seed ^ NQ_JR_MULT) & NQ_JR_MASK; }
+__device__ __forceinline__ int jr_next(long long& st, int bits) {
+    st = (long long) (((unsigned long long) st * (unsigned long long) NQ_JR_MULT + 0xBULL) & (unsigned long long) NQ_JR_MASK);
+    return (int) (st >> (48 - bits));
+}
+__device__ __forceinline__ int jr_next_int_bound(long long& st, int bound) {
+    int r = jr_next(st, 31);
+    int m = bound - 1;
+    if ((bound & m) == 0) r = (int) (((long long) bound * (long long) r) >> 31);
+    else {
+        for (int u = r; (int) ((unsigned) (u - (r = u % bound)) + (unsigned) m) < 0; u = jr_next(st, 31)) { }
+    }
+    return r;
+}
+// stream selector of the parallel decomposition (documented in DESIGN.md): splitmix64 finaliser
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// NQ/PnnQuantizer.java:26-30
+__device__ __constant__ const float k_coeffs[3][3] = {
+    {0.299f, 0.587f, 0.114f},
+    {-0.14713f, -0.28886f, 0.436f},
+    {0.615f, -0.51499f, -0.10001f}
+};
+
+// ------------------------------------------------------------------------------------------------
+// palette staged in LDS: ARGB words + (LAB) the Lab of every entry, getLab(palette[i]) of
+// NQ/PnnLABQuantizer.java:352
+// ------------------------------------------------------------------------------------------------
+struct PalView {
+    const int* argb;     // [K]
+    const float* L;      // [K] (LAB only)
+    const float* A;
+    const float* B;
+};
+
+// ---- nearestColorIndex, cache-miss semantics ----------------------------------------------------
+// RGB: NQ/PnnQuantizer.java:276-310
+__device__ __forceinline__ int nearest_rgb(const DevParams& P, const PalView& pal, int c) {
+    const int K = P.K;
+    int k = 0;
+    if (c_alpha(c) <= 0xF) c = P.transparentColor;
+    if (K > 2 && P.hasAlpha && c_alpha(c) > 0xF) k = 1;
+    double pr = P.PR, pg = P.PG, pb = P.PB, pa = P.PA;
+    if (K < 3) pr = pg = pb = pa = 1;
+    double mindist = 2147483647.0;
+    const int ca = c_alpha(c), cr = c_red(c), cg = c_green(c), cb = c_blue(c);
+    for (int i = k; i < K; ++i) {
+        int c2 = pal.argb[i];
+        double curdist = pa * sqr((double) (c_alpha(c2) - ca));
+        if (curdist > mindist) continue;
+        curdist += pr * sqr((double) (c_red(c2) - cr));
+        if (curdist > mindist) continue;
+        curdist += pg * sqr((double) (c_green(c2) - cg));
+        if (curdist > mindist) continue;
+        curdist += pb * sqr((double) (c_blue(c2) - cb));
+        if (curdist > mindist) continue;
+        mindist = curdist;
+        k = i;
+    }
+    return k;
+}
+
+// LAB: NQ/PnnLABQuantizer.java:337-401
+__device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pal, int c) {
+    const int K = P.K;
+    int k = 0;
+    if (c_alpha(c) <= 0xF) c = P.transparentColor;
+    if (K > 2 && P.hasAlpha && c_alpha(c) > 0xF) k = 1;
+    double mindist = 2147483647.0;
+    const Lab lab1 = RGB2LAB(c);
+    const int ca = c_alpha(c);
+    if (K <= 4) {
+        const int cr = c_red(c), cg = c_green(c), cb = c_blue(c);
+        for (int i = k; i < K; ++i) {
+            int c2 = pal.argb[i];
+            double curdist = P.hasSemi ? sqr((double) (c_alpha(c2) - ca)) / g_tab.exp1_5 : 0;
+            if (curdist > mindist) continue;
+            curdist = sqr((double) (c_red(c2) - cr)) + sqr((double) (c_green(c2) - cg)) + sqr((double) (c_blue(c2) - cb));
+            if (P.hasSemi) curdist += sqr((double) (c_alpha(c2) - ca));
+            if (curdist > mindist) continue;
+            mindist = curdist;
+            k = i;
+        }
+    } else if (P.hasSemi || K < 16) {
+        for (int i = k; i < K; ++i) {
+            double curdist = P.hasSemi ? sqr((double) (c_alpha(pal.argb[i]) - ca)) / g_tab.exp1_5 : 0;
+            if (curdist > mindist) continue;
+            curdist += sqr((double) (pal.L[i] - lab1.L));
+            if (curdist > mindist) continue;
+            curdist += sqr((double) (pal.A[i] - lab1.A));
+            if (curdist > mindist) continue;
+            curdist += sqr((double) (pal.B[i] - lab1.B));
+            if (curdist > mindist) continue;
+            mindist = curdist;
+            k = i;
+        }
+    } else if (K > 32) {
+        for (int i = k; i < K; ++i) {
+            double curdist = (double) fabsf(pal.L[i] - lab1.L);     // hasSemi is false here: curdist starts at 0
+            if (curdist > mindist) continue;
+            curdist += sqrt(sqr((double) (pal.A[i] - lab1.A)) + sqr((double) (pal.B[i] - lab1.B)));
+            if (curdist > mindist) continue;
+            mindist = curdist;
+            k = i;
+        }
+    } else {
+        for (int i = k; i < K; ++i) {
+            Lab lab2; lab2.alpha = (float) c_alpha(pal.argb[i]); lab2.L = pal.L[i]; lab2.A = pal.A[i]; lab2.B = pal.B[i];
+            double curdist = 0;
+            float deltaL = L_prime_div_k_L_S_L(lab1, lab2);
+            curdist += sqr((double) deltaL);
+            if (curdist > mindist) continue;
+            double a1Prime, a2Prime, CPrime1, CPrime2;
+            float deltaC = C_prime_div_k_L_S_L(lab1, lab2, a1Prime, a2Prime, CPrime1, CPrime2);
+            curdist += sqr((double) deltaC);
+            if (curdist > mindist) continue;
+            double barCPrime, barhPrime;
+            float deltaH = H_prime_div_k_L_S_L(lab1, lab2, a1Prime, a2Prime, CPrime1, CPrime2, barCPrime, barhPrime);
+            curdist += sqr((double) deltaH);
+            if (curdist > mindist) continue;
+            curdist += (double) R_T(barCPrime, barhPrime, deltaC, deltaH);
+            if (curdist > mindist) continue;
+            mindist = curdist;
+            k = i;
+        }
+    }
+    return k;
+}
+
+__device__ __forceinline__ int nearest_any(const DevParams& P, const PalView& pal, int c) {
+    return P.kind == 0 ? nearest_rgb(P, pal, c) : nearest_lab(P, pal, c);
+}
+
+// ---- closest[] tuple ------------------------------------------------------------------------------
+// RGB: NQ/PnnQuantizer.java:322-360
+__device__ __forceinline__ void closest_tuple_rgb(const DevParams& P, const PalView& pal, int c, int closest[4]) {
+    const int K = P.K;
+    closest[0] = closest[1] = 0;
+    closest[2] = closest[3] = 2147483647;
+    double pr = P.PR, pg = P.PG, pb = P.PB, pa = P.PA;
+    if (K < 3) pr = pg = pb = pa = 1;
+    const int ca = c_alpha(c), cr = c_red(c), cg = c_green(c), cb = c_blue(c);
+    for (int k = 0; k < K; ++k) {
+        int c2 = pal.argb[k];
+        double err = pr * sqr((double) (c_red(c2) - cr));
+        if (err >= closest[3]) continue;
+        err += pg * sqr((double) (c_green(c2) - cg));
+        if (err >= closest[3]) continue;
+        err += pb * sqr((double) (c_blue(c2) - cb));
+        if (err >= closest[3]) continue;
+        if (P.hasSemi) err += pa * sqr((double) (c_alpha(c2) - ca));
+        if (err < closest[2]) {
+            closest[1] = closest[0]; closest[3] = closest[2];
+            closest[0] = k; closest[2] = j_d2i(err);
+        } else if (err < closest[3]) {
+            closest[1] = k; closest[3] = j_d2i(err);
+        }
+    }
+    if (closest[3] == 2147483647) closest[1] = closest[0];
+}
+// LAB: NQ/PnnLABQuantizer.java:415-461
+__device__ __forceinline__ void closest_tuple_lab(const DevParams& P, const PalView& pal, int c, int closest[4]) {
+    const int K = P.K;
+    closest[0] = closest[1] = 0;
+    closest[2] = closest[3] = 2147483647;
+    const double ratio = P.ratio;
+    const double wr = P.PR * (1 - ratio), wg = P.PG * (1 - ratio), wb = P.PB * (1 - ratio);
+    const int ca = c_alpha(c), cr = c_red(c), cg = c_green(c), cb = c_blue(c);
+    for (int k = 0; k < K; ++k) {
+        int c2 = pal.argb[k];
+        const int dr = c_red(c2) - cr, dg = c_green(c2) - cg, db = c_blue(c2) - cb;
+        double err = wr * sqr((double) dr);
+        if (err >= closest[3]) continue;
+        err += wg * sqr((double) dg);
+        if (err >= closest[3]) continue;
+        err += wb * sqr((double) db);
+        if (err >= closest[3]) continue;
+        if (P.hasSemi) err += P.PA * sqr((double) (c_alpha(c2) - ca));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            err += ratio * sqr((double) (k_coeffs[i][0] * dr));
+            if (err >= closest[3]) break;
+            err += ratio * sqr((double) (k_coeffs[i][1] * dg));
+            if (err >= closest[3]) break;
+            err += ratio * sqr((double) (k_coeffs[i][2] * db));
+            if (err >= closest[3]) break;
+        }
+        if (err < closest[2]) {
+            closest[1] = closest[0]; closest[3] = closest[2];
+            closest[0] = k; closest[2] = j_d2i(err);
+        } else if (err < closest[3]) {
+            closest[1] = k; closest[3] = j_d2i(err);
+        }
+    }
+    if (closest[3] == 2147483647) closest[1] = closest[0];
+}
+
+// ---- the Ditherable the quantizer hands to the ditherers ------------------------------------------
+// (RGB NQ/PnnQuantizer.java:377-391, LAB NQ/PnnLABQuantizer.java:476-490).  `binCache` (nullable) is the
+// reference's nearestMap when it is keyed by histogram bin (REFERENCE_SEQUENTIAL mode only; -1 = empty).
+struct LookupCtx {
+    const DevParams* P;
+    PalView pal;
+    short* binCache;       // [65536] or nullptr (cache-miss semantics)
+    long long rng;         // java.util.Random state of this chain
+    int dither;
+};
+
+__device__ __forceinline__ int nearest_cached(LookupCtx& cx, int c) {
+    const DevParams& P = *cx.P;
+    if (cx.binCache != nullptr && P.binKeyed) {
+        const int offset = getColorIndex(c, P.hasSemi != 0, P.hasAlpha != 0);
+        short got = cx.binCache[offset];
+        if (got >= 0) return got;
+        int k = nearest_any(P, cx.pal, c);
+        cx.binCache[offset] = (short) k;
+        return k;
+    }
+    return nearest_any(P, cx.pal, c);    // a cache keyed by the full colour is transparent: nearest is pure in c
+}
+
+// RGB closestColorIndex: NQ/PnnQuantizer.java:313-375
+__device__ __forceinline__ int closest_rgb(LookupCtx& cx, int c, int pos) {
+    const DevParams& P = *cx.P;
+    if (c_alpha(c) <= 0xF) return nearest_cached(cx, c);
+    int closest[4];
+    closest_tuple_rgb(P, cx.pal, c, closest);
+    const int MAX_ERR = P.K << 2;
+    int idx = (pos + 1) % 2;
+    if (closest[3] * .67 < (closest[3] - closest[2])) idx = 0;
+    else if (closest[0] > closest[1]) idx = pos % 2;
+    if (closest[idx + 2] >= MAX_ERR || (P.hasAlpha && closest[idx] == 0)) return nearest_cached(cx, c);
+    return closest[idx];
+}
+// LAB closestColorIndex: NQ/PnnLABQuantizer.java:407-474
+__device__ __forceinline__ int closest_lab(LookupCtx& cx, int c) {
+    const DevParams& P = *cx.P;
+    if (c_alpha(c) <= 0xF) return nearest_cached(cx, c);
+    int closest[4];
+    closest_tuple_lab(P, cx.pal, c, closest);
+    int idx = 1;
+    if (closest[2] == 0 ||
+        (jr_next_int_bound(cx.rng, 32767) % (int) ((unsigned) closest[3] + (unsigned) closest[2])) <= closest[3])
+        idx = 0;
+    const int MAX_ERR = P.K;
+    if (closest[idx + 2] >= MAX_ERR || closest[idx] == 0 || c_alpha(cx.pal.argb[closest[idx]]) < c_alpha(c))
+        return nearest_cached(cx, c);
+    return closest[idx];
+}
+// Ditherable.nearestColorIndex(palette, c, pos)
+__device__ __forceinline__ int ditherable_lookup(LookupCtx& cx, int c, int pos) {
+    const DevParams& P = *cx.P;
+    if (P.kind == 0) {
+        if (cx.dither) return nearest_cached(cx, c);
+        return closest_rgb(cx, c, pos);
+    }
+    if (P.K <= 4) return nearest_cached(cx, c);
+    return closest_lab(cx, c);
+}
+
+// stage the palette (and its Lab, LAB kind) into LDS; `smem` must hold K ints (+3K floats)
+__device__ __forceinline__ PalView stage_palette(const DevParams& P, const int* __restrict__ g_palette, void* smem) {
+    int* s_argb = (int*) smem;
+    float* s_L = (float*) (s_argb + P.K);
+    float* s_A = s_L + P.K;
+    float* s_B = s_A + P.K;
+    for (int i = threadIdx.x; i < P.K; i += blockDim.x) {
+        int c2 = g_palette[i];
+        s_argb[i] = c2;
+        if (P.kind == 1) {
+            Lab l2 = RGB2LAB(c2);
+            s_L[i] = l2.L; s_A[i] = l2.A; s_B[i] = l2.B;
+        }
+    }
+    __syncthreads();
+    PalView v; v.argb = s_argb; v.L = s_L; v.A = s_A; v.B = s_B;
+    return v;
+}
+__host__ __device__ __forceinline__ size_t palette_smem_bytes(int kind, int K) {
+    return (size_t) K * sizeof(int) + (kind == 1 ? (size_t) 3 * K * sizeof(float) : 0);
+}
+
+} // namespace nq

@@ -1,0 +1,94 @@
+// nq_kernels.h -- host-callable launchers of the gfx950 kernels (defined in nq_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nq {
+
+// scalars of the quantizer object that the per-pixel code needs
+struct DevParams {
+    int kind;              // 0 RGB, 1 LAB
+    int K;                 // palette.length
+    int hasSemi;           // hasSemiTransparency
+    int hasAlpha;          // m_transparentPixelIndex > -1
+    int transparentColor;  // m_transparentColor
+    int isNano;            // NQ/PnnLABQuantizer.java:180
+    int binKeyed;          // nearest cache keyed by histogram bin (LAB: isNano; RGB: !(weight > .015))
+    int nMaxColors;
+    int rewriteA0;         // nMaxColors <= 2: pixels with alpha == 0 read as m_transparentColor (NQ/PnnQuantizer.java:424)
+    int pad;
+    double PR, PG, PB, PA, ratio, weight;   // weight signed
+};
+
+// scalars the GilbertCurve constructor derives (NQ/GilbertCurve.java:50-112) + initWeights tables (:336-354),
+// evaluated once on the host (control plane) and handed to the kernel by value
+struct GilbertConsts {
+    int margin, thresold, DITHER_MAX, ditherMax, sortedByYDiff, hasAlphaW, dither;
+    int hasSaliencies;      // saliencies != null
+    int salSubst;           // saliency computed from the alpha-substituted pixel (pnnquan path, nMaxColors < 128)
+    float beta;
+    double weightAbs;       // the field `weight` (abs value, :61)
+    float weights[25];      // initWeights(DITHER_MAX) (non-sorted mode)
+    float w1[1], w3[3], w7[7]; // initWeights(1|3|7) (sorted mode growth 1 -> 3 -> 7 -> 15)
+};
+
+struct TileGeom {
+    int width, height;
+    int tile_w, tile_h, tiles_x, tiles_y;
+    // visiting order of each tile shape: 0 interior, 1 right edge, 2 bottom edge, 3 corner; entries (dx | dy << 16)
+    const uint32_t* path[4];
+    int path_len[4];
+    int shape_w[4], shape_h[4];
+};
+
+void upload_tables(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s);
+
+void launch_nearest_index(const DevParams& P, const int* d_palette, const int* d_colors, int64_t M, short* d_out, hipStream_t s);
+void launch_closest_tuple(const DevParams& P, const int* d_palette, const int* d_colors, int64_t M, int* d_out4, hipStream_t s);
+// LOOKUP_ONLY: index (+ARGB) of nearestColorIndex(pixel) for every pixel
+void launch_lookup_only(const DevParams& P, const int* d_palette, const int* d_pixels, int64_t N,
+                        unsigned short* d_index, int* d_argb, hipStream_t s);
+
+// GilbertCurve.dither over every tile; writes indices (always) and ARGB (when d_argb != nullptr)
+void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const int* d_pixels,
+                    const int* d_palette, short* d_binCache, long long seed, int sequential, long long* d_rng_state,
+                    unsigned short* d_index, int* d_argb, hipStream_t s);
+// BlueNoise.dither post-pass (NQ/BlueNoise.java:207-222); in-place on d_index, writes d_argb
+void launch_bluenoise(const DevParams& P, const int* d_palette, const int* d_pixels, int width, int height,
+                      float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,
+                      unsigned short* d_index, int* d_argb, hipStream_t s);
+
+
+// ---- palette build (nq_palette.inc) ----
+struct Bins {
+    float* f[4];
+    double* d[4];
+    float* cnt;
+    float* err;
+    int* nn;
+    int* tm;
+    int* mtm;
+};
+struct HistParams { int hasSemi, hasTransp, transparentColor, rewriteTransparent; };
+struct NNParams {
+    int kind, hasSemi, texicab;
+    double ratio, PR, PG, PB, PA;
+    int pgLessThanCoeff;
+};
+struct SortWorkspace {
+    unsigned short *keys_a, *keys_b;
+    int *vals_a, *vals_b;
+    void* tmp; size_t tmp_bytes;
+    unsigned *seg_start, *seg_end;   // [65536]
+};
+size_t sort_temp_bytes(int64_t n);
+void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s);
+void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams& hp, const SortWorkspace& ws,
+                      double* d_hist, hipStream_t s);
+void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, hipStream_t s);
+void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s);
+void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, hipStream_t s);
+void launch_merge(const NNParams& np, const Bins& B, int maxbins, int extbins, int* d_heap, long long* d_stats, hipStream_t s);
+void launch_palette_fill(int kind, const Bins& B, int maxbins, int plen, int* d_palette, int* d_status, hipStream_t s);
+
+} // namespace nq

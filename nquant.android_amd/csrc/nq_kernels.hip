@@ -1,0 +1,134 @@
+// nq_kernels.hip -- the single device translation unit of libnquant_hip.so (gfx950 only).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math (see build.py): Java arithmetic has no
+// fused multiply-add and no fast-math, and parity with the oracle is bit for bit.
+#include "nq_device.h"
+#include "nq_kernels.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace nq {
+__constant__ ConstTables g_tab;
+}
+
+#include "nq_dither.inc"
+#include "nq_palette.inc"
+
+namespace nq {
+
+static const int8_t h_blue[4096] = {
+#include "../../include/nq_blue_noise_64x64.inc"
+};
+
+void upload_tables(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s) {
+    static ConstTables t;     // host staging must outlive the async copy
+    for (int i = 0; i < 256; ++i) t.gamma[i] = gamma[i];
+    t.exp1_5 = exp1_5; t.exp1_75 = exp1_75;
+    for (int i = 0; i < 4096; ++i) t.blue[i] = h_blue[i];
+    (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tab), &t, sizeof t, 0, hipMemcpyHostToDevice, s);
+    (void) hipStreamSynchronize(s);
+}
+
+static inline int grid_for(int64_t n, int block, int cap = 256 * 8) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int) g;
+}
+
+void launch_nearest_index(const DevParams& P, const int* d_palette, const int* d_colors, int64_t M, short* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(nearest_index_kernel, dim3(grid_for(M, 256)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
+                       P, d_palette, d_colors, (long long) M, d_out);
+}
+void launch_closest_tuple(const DevParams& P, const int* d_palette, const int* d_colors, int64_t M, int* d_out4, hipStream_t s) {
+    hipLaunchKernelGGL(closest_tuple_kernel, dim3(grid_for(M, 256)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
+                       P, d_palette, d_colors, (long long) M, d_out4);
+}
+void launch_lookup_only(const DevParams& P, const int* d_palette, const int* d_pixels, int64_t N,
+                        unsigned short* d_index, int* d_argb, hipStream_t s) {
+    hipLaunchKernelGGL(lookup_only_kernel, dim3(grid_for(N, 256, 256 * 16)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
+                       P, d_palette, d_pixels, (long long) N, d_index, d_argb);
+}
+
+void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const int* d_pixels,
+                    const int* d_palette, short* d_binCache, long long seed, int sequential, long long* d_rng_state,
+                    unsigned short* d_index, int* d_argb, hipStream_t s) {
+    const int ntiles = T.tiles_x * T.tiles_y;
+    const int block = 64;
+    const int grid = (ntiles + block - 1) / block;
+    const size_t smem = palette_smem_bytes(P.kind, P.K);
+    if (G.sortedByYDiff)
+        hipLaunchKernelGGL(gilbert_kernel<true>, dim3(grid), dim3(block), smem, s, P, G, T, d_pixels, d_palette, d_binCache,
+                           seed, sequential, d_rng_state, d_index, d_argb);
+    else
+        hipLaunchKernelGGL(gilbert_kernel<false>, dim3(grid), dim3(block), smem, s, P, G, T, d_pixels, d_palette, d_binCache,
+                           seed, sequential, d_rng_state, d_index, d_argb);
+}
+
+void launch_bluenoise(const DevParams& P, const int* d_palette, const int* d_pixels, int width, int height,
+                      float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,
+                      unsigned short* d_index, int* d_argb, hipStream_t s) {
+    const size_t smem = palette_smem_bytes(P.kind, P.K);
+    if (sequential)
+        hipLaunchKernelGGL(bluenoise_seq_kernel, dim3(1), dim3(64), smem, s, P, d_palette, d_pixels, width, height, weight,
+                           d_binCache, d_rng_state, d_index, d_argb);
+    else
+        hipLaunchKernelGGL(bluenoise_kernel, dim3(grid_for((int64_t) width * height, 256, 256 * 16)), dim3(256), smem, s,
+                           P, d_palette, d_pixels, width, height, weight, seed, d_index, d_argb);
+}
+
+// ---- palette build launchers ----
+size_t sort_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void) rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned short*) nullptr, (unsigned short*) nullptr,
+                                     (const int*) nullptr, (int*) nullptr, (size_t) n, 0, 16, (hipStream_t) 0);
+    return bytes;
+}
+void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s) {
+    (void) hipMemsetAsync(d_scan3, 0xFF, 2 * sizeof(long long), s);      // {-1, -1}
+    (void) hipMemsetAsync(d_scan3 + 2, 0, sizeof(long long), s);
+    hipLaunchKernelGGL(prescan_kernel, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, d_pixels, (long long) n,
+                       (long long) index_offset, d_scan3);
+    hipLaunchKernelGGL(prescan_color_kernel, dim3(1), dim3(1), 0, s, d_pixels, (long long) n, (long long) index_offset, d_scan3);
+}
+void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams& hp, const SortWorkspace& ws,
+                      double* d_hist, hipStream_t s) {
+    hipLaunchKernelGGL(bin_keys_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, hp,
+                       ws.keys_a, ws.vals_a);
+    size_t tmp = ws.tmp_bytes;
+    (void) rocprim::radix_sort_pairs(ws.tmp, tmp, (const unsigned short*) ws.keys_a, ws.keys_b, (const int*) ws.vals_a, ws.vals_b,
+                                     (size_t) n, 0, 16, s);
+    (void) hipMemsetAsync(ws.seg_start, 0, 65536 * sizeof(unsigned), s);
+    (void) hipMemsetAsync(ws.seg_end, 0, 65536 * sizeof(unsigned), s);
+    hipLaunchKernelGGL(seg_bounds_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, ws.keys_b, (long long) n,
+                       ws.seg_start, ws.seg_end);
+    if (kind == 1)
+        hipLaunchKernelGGL(hist_segments_kernel<1>, dim3(65536 / 4), dim3(256), 0, s, ws.vals_b, ws.seg_start, ws.seg_end, d_hist);
+    else
+        hipLaunchKernelGGL(hist_segments_kernel<0>, dim3(65536 / 4), dim3(256), 0, s, ws.vals_b, ws.seg_start, ws.seg_end, d_hist);
+}
+void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, hipStream_t s) {
+    if (kind == 1) hipLaunchKernelGGL(compact_means_kernel<1>, dim3(1), dim3(1024), 0, s, d_hists, n_bands, B, d_maxbins);
+    else hipLaunchKernelGGL(compact_means_kernel<0>, dim3(1), dim3(1024), 0, s, d_hists, n_bands, B, d_maxbins);
+}
+void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s) {
+    if (fn == 0 || maxbins <= 0) return;
+    hipLaunchKernelGGL(quanfn_kernel, dim3((maxbins + 255) / 256), dim3(256), 0, s, d_cnt, maxbins, fn);
+}
+void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, hipStream_t s) {
+    if (maxbins <= 0) return;
+    if (np.kind == 1) hipLaunchKernelGGL(find_nn_init_kernel<1>, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
+    else hipLaunchKernelGGL(find_nn_init_kernel<0>, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
+}
+void launch_merge(const NNParams& np, const Bins& B, int maxbins, int extbins, int* d_heap, long long* d_stats, hipStream_t s) {
+    MergeParams mp; mp.maxbins = maxbins; mp.extbins = extbins;
+    const size_t dyn = sizeof(Survivor) * NQ_SURV_PER_WAVE * NQ_MERGE_WAVES;
+    if (np.kind == 1) hipLaunchKernelGGL(merge_kernel<1>, dim3(1), dim3(NQ_MERGE_THREADS), dyn, s, np, B, mp, d_heap, d_stats);
+    else hipLaunchKernelGGL(merge_kernel<0>, dim3(1), dim3(NQ_MERGE_THREADS), dyn, s, np, B, mp, d_heap, d_stats);
+}
+void launch_palette_fill(int kind, const Bins& B, int maxbins, int plen, int* d_palette, int* d_status, hipStream_t s) {
+    (void) hipMemsetAsync(d_status, 0, sizeof(int), s);
+    if (kind == 1) hipLaunchKernelGGL(palette_fill_kernel<1>, dim3(1), dim3(1024), 0, s, B, maxbins, plen, d_palette, d_status);
+    else hipLaunchKernelGGL(palette_fill_kernel<0>, dim3(1), dim3(1024), 0, s, B, maxbins, plen, d_palette, d_status);
+}
+
+} // namespace nq

@@ -1,0 +1,70 @@
+"""Deterministic synthetic ARGB_8888 inputs: splitmix64(seed + i) per pixel.  Used by bench.py and the
+tests; pure numpy (inputs only -- no quantizer arithmetic lives here)."""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed, n, offset=0):
+    """z_i = splitmix64 finaliser of (seed + offset + i + 1) * golden-gamma increments, i = 0..n-1 (uint64 array)."""
+    with np.errstate(over="ignore"):
+        x = (np.arange(n, dtype=np.uint64) + np.uint64(offset) + np.uint64(seed)) * np.uint64(1)
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _pack(a, r, g, b):
+    v = (a.astype(np.uint32) << np.uint32(24)) | (r.astype(np.uint32) << np.uint32(16)) | \
+        (g.astype(np.uint32) << np.uint32(8)) | b.astype(np.uint32)
+    return v.view(np.int32)
+
+
+def uniform_rgb(width, height, seed):
+    """type (a): uniform random opaque RGB (worst case for pnnquan: every histogram bin occupied at >= 1024^2)."""
+    z = splitmix64(seed, width * height)
+    rgb = (z & np.uint64(0xFFFFFF)).astype(np.uint32)
+    return (rgb | np.uint32(0xFF000000)).view(np.int32).reshape(height, width)
+
+
+def gradient_noise(width, height, seed, noise=24):
+    """type (b): smooth 2-D gradients + per-channel noise, opaque.  R follows x, G follows y, B follows a diagonal
+    wave; `noise` is the peak-to-peak amplitude of the uniform per-channel noise (8-bit units)."""
+    n = width * height
+    z = splitmix64(seed, n)
+    y, x = np.divmod(np.arange(n, dtype=np.int64), width)
+    fx = x / max(width - 1, 1)
+    fy = y / max(height - 1, 1)
+    nr = ((z >> np.uint64(0)) & np.uint64(0xFF)).astype(np.float64) / 255.0 - 0.5
+    ng = ((z >> np.uint64(8)) & np.uint64(0xFF)).astype(np.float64) / 255.0 - 0.5
+    nb = ((z >> np.uint64(16)) & np.uint64(0xFF)).astype(np.float64) / 255.0 - 0.5
+    r = 255.0 * fx + noise * nr
+    g = 255.0 * fy + noise * ng
+    b = 127.5 * (1.0 + np.sin(2.0 * np.pi * (0.75 * fx + 0.5 * fy))) + noise * nb
+    r = np.clip(np.rint(r), 0, 255).astype(np.uint32)
+    g = np.clip(np.rint(g), 0, 255).astype(np.uint32)
+    b = np.clip(np.rint(b), 0, 255).astype(np.uint32)
+    a = np.full(n, 255, np.uint32)
+    return _pack(a, r, g, b).reshape(height, width)
+
+
+def with_alpha(img, seed, p_transparent=0.01, p_semi=0.05):
+    """Variant exercising the transparency paths: ~1 % alpha == 0 pixels and ~5 % alpha in [16, 223]."""
+    flat = img.reshape(-1).view(np.uint32).copy()
+    z = splitmix64(seed ^ 0xA1FA, flat.size)
+    u = (z & np.uint64(0xFFFF)).astype(np.float64) / 65536.0
+    a = np.full(flat.size, 255, np.uint32)
+    semi = u < (p_transparent + p_semi)
+    a[semi] = (16 + ((z[semi] >> np.uint64(16)) % np.uint64(208))).astype(np.uint32)
+    a[u < p_transparent] = 0
+    out = (flat & np.uint32(0x00FFFFFF)) | (a << np.uint32(24))
+    return out.view(np.int32).reshape(img.shape)
+
+
+def few_colors(width, height, seed, ncolors):
+    """Image drawn from `ncolors` distinct opaque colours (exercises the few-bins branches)."""
+    z = splitmix64(seed, width * height)
+    pal = (splitmix64(seed ^ 0x5EED, ncolors) & np.uint64(0xFFFFFF)).astype(np.uint32) | np.uint32(0xFF000000)
+    return pal[(z % np.uint64(ncolors)).astype(np.int64)].view(np.int32).reshape(height, width)

@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, exports every symbol include/nquant_abi.h
+declares, and refuses to compute without a HIP device (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import HAS_GPU, ROOT
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "nquant_abi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nq_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(nq):
+    L = nq.load_library()
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), "libnquant_hip.so does not export %s" % name
+    assert sorted(nq.abi_symbols()) == declared
+    assert L.nq_abi_version() == 1
+
+
+def test_library_does_not_link_the_oracle(nq):
+    import subprocess
+    out = subprocess.run(["ldd", nq.library_path()], capture_output=True, text=True).stdout
+    assert "nq_oracle" not in out
+    syms = subprocess.run(["nm", "-D", nq.library_path()], capture_output=True, text=True).stdout
+    assert "nqo_" not in syms
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-device error path")
+def test_no_cpu_fallback(nq):
+    with pytest.raises(nq.NqError) as e:
+        nq.PnnLABQuantizer(np.zeros((8, 8), np.int32))
+    assert e.value.status == -5 and "no CPU fallback" in str(e.value)
+
+
+def test_host_mirror_argument_checks(nq):
+    with pytest.raises(TypeError):
+        nq.PnnQuantizer(np.zeros((4, 4), np.float32))
+
+
+def test_params_struct_layout_matches_oracle(nq, oracle):
+    import ctypes as C
+    assert C.sizeof(nq.Params) == C.sizeof(oracle.Params) == 96
+    assert [f for f, _ in nq.Params._fields_] == [f for f, _ in oracle.Params._fields_]
+
+
+def test_synth_is_deterministic(nq):
+    from nquant.android_amd import synth
+    a = synth.uniform_rgb(64, 64, 1)
+    assert a.dtype == np.int32 and a.shape == (64, 64)
+    assert (a.view(np.uint32) >> 24 == 255).all()
+    assert int(a.view(np.uint32).astype(np.uint64).sum()) == int(synth.uniform_rgb(64, 64, 1).view(np.uint32).astype(np.uint64).sum())
+    g = synth.gradient_noise(96, 64, 3)
+    assert g.shape == (64, 96) and (g.view(np.uint32) >> 24 == 255).all()
+    t = synth.with_alpha(g, 3)
+    al = t.view(np.uint32) >> 24
+    assert (al == 0).any() and ((al > 15) & (al < 0xE0)).any()

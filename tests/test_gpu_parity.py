@@ -1,0 +1,228 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.  Bit-exact bar for every
+integer / index / palette output (SURVEY.md 8c contract items 1-5); PARALLEL_TILED is compared bit for bit against the
+oracle's tiled restatement and its deviation from the sequential reference is reported as a CIE76 deltaE."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nquant.android_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SEQ, TILED, LOOKUP = 0, 1, 2
+
+
+def _copy_params(src, dst_cls):
+    p = dst_cls()
+    for f, _ in dst_cls._fields_:
+        setattr(p, f, getattr(src, f))
+    return p
+
+
+def _colors(n, seed, alpha_mix=False):
+    z = synth.splitmix64(seed, n)
+    c = (z & np.uint64(0xFFFFFF)).astype(np.uint32)
+    a = np.full(n, 255, np.uint32)
+    if alpha_mix:
+        a = ((z >> np.uint64(24)) & np.uint64(0xFF)).astype(np.uint32)
+        a[::7] = 255
+        a[::11] = 0
+    return (c | (a << np.uint32(24))).view(np.int32)
+
+
+def _oracle_palette(oracle, kind, img, K):
+    q = oracle.OracleQuantizer(kind, img)
+    q.prescan(K)
+    pal = q.pnnquan(K)
+    return q, pal
+
+
+CASES = [  # kind, K, image factory, alpha colours
+    (1, 256, lambda: synth.gradient_noise(96, 96, 11), False),     # LAB K>32: |dL| + sqrt(dA^2+dB^2)
+    (1, 24, lambda: synth.gradient_noise(64, 64, 12), False),      # LAB 16..32: CIEDE2000
+    (1, 8, lambda: synth.uniform_rgb(48, 48, 13), False),          # LAB K<16: squared Lab
+    (1, 4, lambda: synth.uniform_rgb(48, 48, 14), False),          # LAB K<=4: RGB
+    (1, 64, lambda: synth.with_alpha(synth.gradient_noise(64, 64, 15), 15), True),   # semi-transparent
+    (0, 16, lambda: synth.uniform_rgb(64, 64, 1), False),          # RGB
+    (0, 256, lambda: synth.with_alpha(synth.uniform_rgb(96, 96, 16), 16), True),
+]
+
+
+@pytest.mark.parametrize("kind,K,mk,alpha", CASES)
+def test_nearest_and_closest_bit_exact(nq, oracle, kind, K, mk, alpha):
+    img = mk()
+    oq, pal = _oracle_palette(oracle, kind, img, K)
+    cols = _colors(40000, 100 + K, alpha)
+    want_idx = oq.nearest_index(pal, cols)
+    want_tup = oq.closest_tuple(pal, cols)
+    gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img)
+    gq.set_params(_copy_params(oq.params, nq.Params))
+    got_idx = gq.nearestColorIndex(pal, cols)
+    got_tup = gq.closestTuple(pal, cols)
+    assert (got_idx != want_idx).sum() == 0, "nearest mismatches: %d" % (got_idx != want_idx).sum()
+    assert (got_tup != want_tup).any(axis=1).sum() == 0
+
+
+PAL_CASES = [
+    (0, 16, lambda: synth.uniform_rgb(64, 64, 1)),                              # BASELINE cfg 1
+    (0, 256, lambda: synth.gradient_noise(128, 128, 21)),
+    (0, 8, lambda: synth.with_alpha(synth.uniform_rgb(64, 64, 22), 22)),        # quan_rt = -1 (cbrt)
+    (1, 256, lambda: synth.uniform_rgb(112, 112, 2)),
+    (1, 256, lambda: synth.gradient_noise(160, 160, 3)),
+    (1, 64, lambda: synth.with_alpha(synth.gradient_noise(96, 96, 23), 23)),
+    (1, 16, lambda: synth.gradient_noise(96, 96, 24)),
+    (1, 300, lambda: synth.uniform_rgb(96, 96, 25)),
+]
+
+
+@pytest.mark.parametrize("kind,K,mk", PAL_CASES)
+def test_pnnquan_palette_and_scalars_bit_exact(nq, oracle, kind, K, mk):
+    img = mk()
+    oq, want = _oracle_palette(oracle, kind, img, K)
+    gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img)
+    got = gq.pnnquan(K)
+    op, gp = oq.params, gq.params
+    for f in ("hasSemiTransparency", "transparentPixelIndex", "transparentColor", "maxbins", "quan_rt", "isNano", "texicab",
+              "paletteLength", "PR", "PG", "PB", "PA", "ratio", "weight"):
+        assert getattr(op, f) == getattr(gp, f), (f, getattr(op, f), getattr(gp, f))
+    assert len(got) == len(want)
+    assert (got != want).sum() == 0, "palette mismatches: %d of %d" % ((got != want).sum(), len(want))
+
+
+def _lab_of(oracle, argb):
+    u, inv = np.unique(argb.reshape(-1), return_inverse=True)
+    lab = np.array([oracle.rgb2lab(int(c))[1:] for c in u], np.float64)
+    return lab[inv]
+
+
+DITHER_CASES = [
+    (1, 256, True, lambda: synth.gradient_noise(128, 96, 31), (16, 16)),
+    (1, 256, True, lambda: synth.uniform_rgb(80, 72, 32), (16, 16)),
+    (1, 256, False, lambda: synth.gradient_noise(96, 96, 33), (16, 16)),      # + BlueNoise pass
+    (1, 64, True, lambda: synth.with_alpha(synth.gradient_noise(96, 80, 34), 34), (16, 8)),
+    (1, 16, True, lambda: synth.gradient_noise(64, 64, 35), (16, 16)),
+    (1, 256, True, lambda: synth.few_colors(96, 96, 36, 3000), (16, 16)),      # few bins -> sorted-by-yDiff queue
+    (0, 16, False, lambda: synth.uniform_rgb(64, 64, 1), (16, 16)),            # cfg 1 semantics
+    (0, 256, True, lambda: synth.gradient_noise(96, 96, 37), (32, 8)),
+    (0, 256, False, lambda: synth.with_alpha(synth.uniform_rgb(72, 72, 38), 38), (16, 16)),
+]
+
+
+@pytest.mark.parametrize("kind,K,dither,mk,tile", DITHER_CASES)
+def test_dither_tiled_bit_exact_vs_oracle_tiled(nq, oracle, kind, K, dither, mk, tile):
+    img = mk()
+    seed = 1234
+    oq, pal = _oracle_palette(oracle, kind, img, K)
+    params = _copy_params(oq.params, nq.Params)
+    oq.set_seed(seed)
+    want_argb, want_idx = oq.dither(pal, dither, tile=tile)
+    gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=TILED, seed=seed, tile=tile)
+    gq.set_params(params)
+    got_argb, got_idx = gq.dither(pal, dither)
+    bad = (got_idx.astype(np.int32) != want_idx).sum()
+    assert bad == 0, "index mismatches: %d of %d" % (bad, want_idx.size)
+    assert (got_argb != want_argb).sum() == 0
+
+
+SEQ_CASES = [
+    (1, 256, True, lambda: synth.gradient_noise(48, 40, 41)),
+    (1, 64, True, lambda: synth.uniform_rgb(40, 40, 42)),
+    (0, 16, False, lambda: synth.uniform_rgb(64, 64, 1)),
+    (0, 256, False, lambda: synth.gradient_noise(48, 48, 43)),
+    (1, 16, False, lambda: synth.gradient_noise(40, 48, 44)),
+]
+
+
+@pytest.mark.parametrize("kind,K,dither,mk", SEQ_CASES)
+def test_reference_sequential_bit_exact_vs_oracle(nq, oracle, kind, K, dither, mk):
+    img = mk()
+    seed = 77
+    oq, pal = _oracle_palette(oracle, kind, img, K)
+    params = _copy_params(oq.params, nq.Params)
+    oq.set_seed(seed)
+    want_argb, want_idx = oq.dither(pal, dither)
+    gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=SEQ, seed=seed)
+    gq.set_params(params)
+    got_argb, got_idx = gq.dither(pal, dither)
+    assert (got_idx.astype(np.int32) != want_idx).sum() == 0
+    assert (got_argb != want_argb).sum() == 0
+
+
+def test_lookup_only_1024_bit_exact(nq, oracle):
+    """BASELINE cfg 2: 1024x1024, LAB, 256 colours, no dither: index map == per-pixel nearestColorIndex of the oracle."""
+    img = synth.uniform_rgb(1024, 1024, 2)
+    small = synth.uniform_rgb(96, 96, 2)
+    oq, pal = _oracle_palette(oracle, 1, small, 256)
+    params = _copy_params(oq.params, nq.Params)
+    gq = nq.PnnLABQuantizer(img, mode=LOOKUP)
+    gq.set_params(params)
+    got_argb, got_idx = gq.dither(pal, False)
+    want = oq.nearest_index(pal, img.reshape(-1)).reshape(img.shape)
+    assert (got_idx.astype(np.int32) != want).sum() == 0
+    assert (got_argb != pal[want]).sum() == 0
+
+
+def test_convert_end_to_end_tiled(nq, oracle):
+    """convert(256, true) on the GPU == oracle prescan + pnnquan + tiled dither."""
+    img = synth.gradient_noise(144, 112, 51)
+    seed = 5
+    oq, pal = _oracle_palette(oracle, 1, img, 256)
+    oq.set_seed(seed)
+    want_argb, want_idx = oq.dither(pal, True, tile=(16, 16))
+    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=seed)
+    out = gq.convert(256, True)
+    assert (out.palette != pal).sum() == 0
+    assert (out.index.astype(np.int32) != want_idx).sum() == 0
+    assert (out.argb != want_argb).sum() == 0
+    assert (out.argb == out.palette[out.index]).all()
+    ms = gq.stage_ms()
+    assert ms["total"] > 0
+
+
+def test_tiled_deviation_from_sequential_reference_is_small(nq, oracle):
+    """PARALLEL_TILED vs the sequential reference semantics: per-pixel CIE76 deltaE against the source must not be
+    worse than the sequential oracle's by more than 10 %, and the two results stay close on average."""
+    img = synth.gradient_noise(128, 128, 61)
+    oq, pal = _oracle_palette(oracle, 1, img, 256)
+    params = _copy_params(oq.params, nq.Params)
+    oq.set_seed(9)
+    seq_argb, _ = oq.dither(pal, True)
+    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=9)
+    gq.set_params(params)
+    got_argb, _ = gq.dither(pal, True)
+    src = _lab_of(oracle, img)
+    e_seq = np.linalg.norm(_lab_of(oracle, seq_argb) - src, axis=1).mean()
+    e_gpu = np.linalg.norm(_lab_of(oracle, got_argb) - src, axis=1).mean()
+    assert e_gpu <= 1.10 * e_seq + 0.05, (e_gpu, e_seq)
+    d = np.linalg.norm(_lab_of(oracle, got_argb) - _lab_of(oracle, seq_argb), axis=1)
+    assert d.mean() < 6.0, d.mean()       # stated tolerance: mean CIE76 deltaE between tiled and sequential output
+
+
+def test_full_size_properties_4096(nq):
+    """BASELINE cfg 3 at full size through size-independent properties: every output pixel is the palette entry of its
+    index, indices are in range, the palette has 256 distinct-bin survivors, and the run is reproducible."""
+    import torch
+    W = H = 4096
+    img = synth.gradient_noise(W, H, 3)
+    d_in = torch.from_numpy(img.reshape(-1)).cuda()
+    d_out = torch.empty(W * H, dtype=torch.int32, device="cuda")
+    d_idx = torch.empty(W * H, dtype=torch.int16, device="cuda")
+    q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), mode=TILED, seed=3)
+    q.width, q.height = W, H
+    pal = q.convert_device(d_in.data_ptr(), 256, True, d_out.data_ptr(), d_idx.data_ptr())
+    torch.cuda.synchronize()
+    assert len(pal) == 256
+    idx = d_idx.cpu().numpy().view(np.uint16).astype(np.int64)
+    out = d_out.cpu().numpy()
+    assert idx.max() < 256
+    assert (out == pal[idx]).all()
+    assert len(np.unique(idx)) > 200
+    first = out.copy()
+    pal2 = q.convert_device(d_in.data_ptr(), 256, True, d_out.data_ptr(), d_idx.data_ptr())
+    torch.cuda.synchronize()
+    assert (pal2 == pal).all() and (d_out.cpu().numpy() == first).all()
+    # mean quantisation error in sRGB units stays small for a 256-colour palette on a smooth image
+    def ch(a, s): return ((a.view(np.uint32) >> s) & 0xFF).astype(np.float64)
+    err = np.mean([np.abs(ch(out, s) - ch(img.reshape(-1), s)).mean() for s in (0, 8, 16)])
+    assert err < 12.0, err
