@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json: Mpixels/s, 4096x4096 RGBA -> 256-colour PnnLAB + dither.
+
+One "step" = one whole convert(256, dither=true) of a 4096x4096 ARGB image that is already resident in HBM:
+alpha pre-scan, histogram, find_nn, merge loop, palette fill, gilbert-curve error diffusion (PARALLEL_TILED).
+Multi-GPU (driver: torch.distributed.run, one rank per GPU): every rank converts its own image (independent units,
+no data-path collective; RCCL only for the barrier / max-over-ranks of the time) -> "scaling": "weak".
+
+Prints ONE JSON line on rank 0 (contract in the round prompt) with two extra objects:
+  roofline     -- dominant per-pixel kernel (gilbert_kernel = nearest-colour + dither pass), algorithmic bytes
+                  8 B/pixel (4 B ARGB read + 4 B ARGB write) / its average duration measured with HIP
+                  events on the launch stream inside the timed region, against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (C restatement of the reference's sequential Java path, 1 core) on a bounded sample
+                  of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+BYTES_PER_PIXEL = 8             # 4 B ARGB read + 4 B ARGB write
+
+
+def cpu_baseline(workload, sample):
+    """Times the oracle (sequential C restatement of the reference, one core) on a sample x sample image of the same
+    generator; ~10-30 s of CPU work."""
+    import oracle_lib
+    from nquant.android_amd import synth
+    img = synth.gradient_noise(sample, sample, 3) if workload == "gradient_noise" else synth.uniform_rgb(sample, sample, 3)
+    q = oracle_lib.OracleQuantizer(1, img, seed=3)
+    t0 = time.perf_counter()
+    q.convert(256, True)
+    dt = time.perf_counter() - t0
+    st = q.stage_seconds()
+    return {"value": round(sample * sample / dt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": "%dx%d %s, whole convert(256,true), sequential C restatement of the reference Java path, %.1f s "
+                      "(pnnquan %.1f s, dither %.1f s)" % (sample, sample, workload, dt,
+                                                            st["histogram"] + st["nn_init"] + st["merge"], st["gilbert"]),
+            "nproc": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform"])
+    ap.add_argument("--tile", type=int, default=16)
+    ap.add_argument("--cpu-sample", type=int, default=512, help="side of the CPU-baseline sample image (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import nquant.android_amd as nq
+    from nquant.android_amd import synth
+    nq.build_library()
+
+    W = H = args.size
+    npx = W * H
+    seed = 3 + rank
+    img = synth.gradient_noise(W, H, seed) if args.workload == "gradient_noise" else synth.uniform_rgb(W, H, seed)
+    d_in = torch.from_numpy(img.reshape(-1)).cuda()
+    d_out = torch.empty(npx, dtype=torch.int32, device="cuda")
+    d_idx = torch.empty(npx, dtype=torch.int16, device="cuda")
+    q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), device=local_rank, mode=nq.MODE_PARALLEL_TILED, seed=seed,
+                           tile=(args.tile, args.tile))
+    q.width, q.height = W, H
+    stream = torch.cuda.current_stream()
+    q.set_stream(stream.cuda_stream)
+
+    def step():
+        return q.convert_device(d_in.data_ptr(), 256, True, d_out.data_ptr(), d_idx.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stages = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pal = step()
+        for k, v in q.stage_ms().items():          # HIP events recorded on the launch stream, per stage
+            stages[k] = stages.get(k, 0.0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stages = {k: v / max(args.steps, 1) for k, v in stages.items()}
+
+    if rank == 0:
+        p = q.params
+        kernel_ms = stages["dither"]
+        achieved = BYTES_PER_PIXEL * npx / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "Mpixels/sec, 4096x4096 RGBA -> 256-colour PnnLAB + dither",
+            "value": round(world * args.steps * npx / dt / 1e6, 3),
+            "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dx%d ARGB_8888 %s (seed 3+rank), PnnLABQuantizer.convert(256, dither=true), "
+                                   "PARALLEL_TILED %dx%d tiles, one image per rank per step" % (W, H, args.workload, args.tile, args.tile),
+                       "palette": int(len(pal)), "maxbins": int(p.maxbins), "parallelism": "1 image per GPU, no collective"},
+            "stages_ms": {k: round(v, 3) for k, v in stages.items()},
+            "pass_mpixels_s": round(npx / (kernel_ms * 1e-3) / 1e6, 1) if kernel_ms > 0 else None,
+            "roofline": {"bound": "hbm", "kernel": "gilbert_kernel<false> (per-pixel nearest/closest colour + error diffusion)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * npx, "kernel_ms": round(kernel_ms, 3)},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,28 @@ def library_path():
     return os.path.join(_HERE, "libnquant_hip.so")
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  libnquant_hip.so needs `libamdhip64.so.7`; a PyTorch-ROCm wheel bundles its own copy
+    (same SONAME) and always loads it by file name, so if the system runtime got in first the process would hold two
+    runtimes and the second one sees no GPU.  When torch is installed, load ITS runtime first (cheap: no torch import);
+    the dynamic loader then resolves our NEEDED entry and torch's to that one copy, and torch tensors / streams are
+    valid in our launches.  NQ_HIP_RUNTIME=<path> overrides, NQ_HIP_RUNTIME=system skips."""
+    choice = os.environ.get("NQ_HIP_RUNTIME", "")
+    if choice == "system":
+        return
+    cand = choice
+    if not cand:
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")
+            if spec is not None and spec.submodule_search_locations:
+                cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        except Exception:
+            cand = ""
+    if cand and os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Loads libnquant_hip.so (built in-tree by build.py).  Raises if it is missing: there is no fallback."""
     global _LIB
@@ -60,6 +82,7 @@ def load_library():
     path = library_path()
     if not os.path.exists(path):
         raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    _preload_hip_runtime()
     L = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     L.nq_abi_version.restype = i32
