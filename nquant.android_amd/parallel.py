@@ -1,0 +1,78 @@
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests).  The path shards two ways:
+
+* independent images (BASELINE cfg 4): frame f -> rank f mod world, no data-path collective;
+* one image cut into row bands (cfg 5): ONE exchange step -- the pre-scan scalars (max / sum) and the 65536x5 f64
+  histogram partials (2.6 MB per rank, all-gather so that every rank adds them in band order) -- then every rank builds
+  the same palette and dithers its own band.
+
+Only tensors cross this module; the quantizer calls go through the C ABI (host.py)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HIST_BINS, HIST_STRIDE = 65536, 5
+
+
+def shard_frames(n_frames, rank, world):
+    """Frames of a batch owned by `rank` (round robin)."""
+    return list(range(rank, n_frames, world))
+
+
+def band_bounds(height, rank, world):
+    """Row band [y0, y1) of `rank`: equal bands, the remainder rows go to the first bands."""
+    base, rem = divmod(height, world)
+    y0 = rank * base + min(rank, rem)
+    return y0, y0 + base + (1 if rank < rem else 0)
+
+
+def reduce_scan(scan3, group=None):
+    """scan3 = int64[3] {max global index of an alpha==0 pixel or -1, its colour, count of semi-transparent pixels} of this
+    band.  Returns the image-wide triple: the LAST transparent pixel wins (NQ/PnnQuantizer.java:419-422), counts add."""
+    world = dist.get_world_size(group)
+    gathered = [torch.empty_like(scan3) for _ in range(world)]
+    dist.all_gather(gathered, scan3, group=group)
+    allv = torch.stack(gathered).cpu()
+    winner = int(torch.argmax(allv[:, 0]))
+    idx = int(allv[winner, 0])
+    color = int(allv[winner, 1]) if idx >= 0 else -1
+    semi = int(allv[:, 2].sum())
+    return idx, color, semi
+
+
+def gather_histograms(hist, group=None):
+    """hist = f64[65536*5] partial of this band -> f64[world, 65536*5] in band (= rank) order on every rank."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(hist.shape), dtype=hist.dtype, device=hist.device)
+    dist.all_gather_into_tensor(out, hist.contiguous(), group=group) if hasattr(dist, "all_gather_into_tensor") and hist.is_cuda \
+        else dist.all_gather(list(out.unbind(0)), hist.contiguous(), group=group)
+    return out
+
+
+def max_over_ranks(seconds, device="cpu", group=None):
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_argb, d_out_index=None, group=None):
+    """One image tiled over the ranks of `group` (GPU only).  q: a PnnQuantizer/PnnLABQuantizer of this rank; d_band: this
+    rank's rows as a CUDA int32 tensor.  Returns the (shared) palette."""
+    import ctypes as C
+    L = q._L
+    n = width * band_rows
+    scan3 = torch.empty(3, dtype=torch.int64, device=d_band.device)
+    q._check(L.nq_band_scan_device(q._h, C.c_void_p(d_band.data_ptr()), n, y0 * width, nMaxColors, C.c_void_p(scan3.data_ptr())))
+    idx, color, semi = reduce_scan(scan3, group)
+    q._check(L.nq_set_scan(q._h, nMaxColors, idx, C.c_uint32(color & 0xFFFFFFFF), semi))
+    hist = torch.empty(HIST_BINS * HIST_STRIDE, dtype=torch.float64, device=d_band.device)
+    q._check(L.nq_band_histogram_device(q._h, C.c_void_p(d_band.data_ptr()), n, C.c_void_p(hist.data_ptr())))
+    hists = gather_histograms(hist, group)
+    pal = np.zeros(max(nMaxColors, 2), np.int32)
+    K = C.c_int32(0)
+    q._check(L.nq_palette_from_histograms_device(q._h, C.c_void_p(hists.data_ptr()), hists.shape[0], nMaxColors,
+                                                 pal.ctypes.data, C.byref(K)))
+    pal = pal[:K.value].copy()
+    q.width, q.height = width, band_rows
+    q.dither_device(d_band.data_ptr(), pal, dither, d_out_argb.data_ptr(), d_out_index.data_ptr() if d_out_index is not None else 0)
+    return pal

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the CPU oracle (the reference is Java and cannot run here; it ships no golden
+vectors of its own).  Inputs come from the seeded generators in nquant.android_amd/synth.py, so the
+fixtures hold only the expected outputs.  Run from the repo root: python tests/golden/make_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O                                    # noqa: E402
+from nquant.android_amd import synth                      # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    # BASELINE cfg 1: 64x64 uniform RGB seed 1, PnnQuantizer.convert(16, dither=false): fully deterministic
+    "cfg1_rgb16_64x64": dict(kind=0, K=16, dither=False, img=lambda: synth.uniform_rgb(64, 64, 1), seed=0, tile=None),
+    # LAB 256 colours, sequential reference semantics with an injected seed
+    "lab256_seq_64x64": dict(kind=1, K=256, dither=True, img=lambda: synth.gradient_noise(64, 64, 2), seed=7, tile=None),
+    # LAB 256 colours, the tiled decomposition the GPU runs (16x16 tiles)
+    "lab256_tiled_96x80": dict(kind=1, K=256, dither=True, img=lambda: synth.gradient_noise(96, 80, 3), seed=7, tile=(16, 16)),
+    "lab256_tiled_nodither_96x80": dict(kind=1, K=256, dither=False, img=lambda: synth.gradient_noise(96, 80, 3), seed=7, tile=(16, 16)),
+    "lab64_alpha_tiled_64x64": dict(kind=1, K=64, dither=True, img=lambda: synth.with_alpha(synth.gradient_noise(64, 64, 4), 4), seed=5, tile=(16, 16)),
+}
+
+
+def run_case(c):
+    img = c["img"]()
+    q = O.OracleQuantizer(c["kind"], img, seed=c["seed"])
+    q.prescan(c["K"])
+    pal = q.pnnquan(c["K"])
+    p = q.params
+    q.set_seed(c["seed"])
+    argb, idx = q.dither(pal, c["dither"], tile=c["tile"])
+    scal = np.array([p.hasSemiTransparency, p.transparentPixelIndex, p.transparentColor, p.isNano, p.texicab, p.quan_rt,
+                     p.maxbins, p.paletteLength], np.int64)
+    dbl = np.array([p.PR, p.PG, p.PB, p.PA, p.ratio, p.weight], np.float64)
+    return dict(palette=pal, index=idx.astype(np.uint16), argb=argb, scalars=scal, doubles=dbl, distinct=np.int64(p.distinctColors))
+
+
+if __name__ == "__main__":
+    for name, c in CASES.items():
+        r = run_case(c)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)
+        print(name, "K", len(r["palette"]), "maxbins", int(r["scalars"][6]))
