@@ -134,6 +134,7 @@ def main():
                                    "PARALLEL_TILED %dx%d tiles, one image per rank per step" % (W, H, args.workload, args.tile, args.tile),
                        "palette": int(len(pal)), "maxbins": int(p.maxbins), "parallelism": "1 image per GPU, no collective"},
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
+            "merge_stats": q.merge_stats(),
             "pass_mpixels_s": round(npx / (kernel_ms * 1e-3) / 1e6, 1) if kernel_ms > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "gilbert_kernel<false> (per-pixel nearest/closest colour + error diffusion)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -150,6 +150,11 @@ int nq_palette_from_histograms_device(nq_handle* h, const double* d_hists, int n
  * events on the handle's stream: {prescan, histogram, nn_init, merge, palette_fill, dither, bluenoise, total}. */
 #define NQ_N_STAGES 8
 int nq_get_stage_ms(const nq_handle* h, float* out8);
+/* Counters of the last merge loop (diagnostics), 16 values: {find_nn calls, merges, 100 MHz ticks inside find_nn, ticks in
+ * the sequential heap/merge section, live-list rebuilds, find_nn list overflows, candidates evaluated exactly, ticks in
+ * the bound pass, ticks in the exact pass, ticks in the replay, 64-candidate chunks visited, chunks that ran the level-1
+ * bound, chunks that ran the tight bound, chunks that listed a candidate, 0, 0}. */
+int nq_get_merge_stats(const nq_handle* h, int64_t* out16);
 
 #ifdef __cplusplus
 }

@@ -138,7 +138,11 @@ struct nq_handle {
     DevBuf<int> d_palette, d_in, d_out_argb, d_colors, d_tuple;
     DevBuf<unsigned short> d_out_index, keys_a, keys_b;
     DevBuf<short> d_bincache, d_short;
-    DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..5] merge stats
+    DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..11] merge stats
+    DevBuf<int> live3;                // merge loop: two live lists + position index
+    DevBuf<float> scan_f;             // merge loop: position-indexed scan arrays (two generations)
+    DevBuf<int> scan_i;
+    long long merge_stats[16] = {0};
     DevBuf<int> d_ints;               // [0] maxbins, [1] status
     DevBuf<int> vals_a, vals_b, heap;
     DevBuf<unsigned char> sort_tmp;
@@ -172,7 +176,7 @@ int use_device(nq_handle* h) {
         }
         upload_tables(gamma, std::exp(1.5), std::exp(1.75), h->stream);
         NQ_HIP(h, hipGetLastError());
-        NQ_HIP(h, h->d_scalars.reserve(8));
+        NQ_HIP(h, h->d_scalars.reserve(32));
         NQ_HIP(h, h->d_ints.reserve(4));
         NQ_HIP(h, h->d_bincache.reserve(65536));
         for (auto& e : h->ev) NQ_HIP(h, hipEventCreate(&e));
@@ -223,7 +227,9 @@ int reserve_palette_ws(nq_handle* h, int64_t n) {
     NQ_HIP(h, h->seg.reserve(2 * 65536));
     NQ_HIP(h, h->hist.reserve((size_t) 65536 * 5));
     NQ_HIP(h, h->binf.reserve((size_t) 6 * 65536)); NQ_HIP(h, h->bind.reserve((size_t) 4 * 65536));
-    NQ_HIP(h, h->bini.reserve((size_t) 3 * 65536)); NQ_HIP(h, h->heap.reserve(65536 + 2));
+    NQ_HIP(h, h->bini.reserve((size_t) 3 * 65536)); NQ_HIP(h, h->heap.reserve(2 * (65536 + 2)));
+    NQ_HIP(h, h->live3.reserve((size_t) 3 * 65536));
+    NQ_HIP(h, h->scan_f.reserve((size_t) 2 * 6 * 65536)); NQ_HIP(h, h->scan_i.reserve((size_t) 2 * 65536));
     return NQ_OK;
 }
 
@@ -323,7 +329,7 @@ int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMax
         }
     }
     const int extbins = maxbins - nMaxColors;
-    launch_merge(np, B, maxbins, extbins, h->heap.p, h->d_scalars.p + 4, h->stream);
+    launch_merge(np, B, maxbins, extbins, h->heap.p, h->live3.p, h->scan_f.p, h->scan_i.p, h->d_scalars.p + 4, h->stream);
     rec(h, 4);
     const int plen = extbins > 0 ? nMaxColors : maxbins;
     NQ_HIP(h, h->d_palette.reserve((size_t) std::max(plen, 2)));
@@ -333,6 +339,7 @@ int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMax
     int status = 0;
     NQ_HIP(h, hipMemcpyAsync(out_palette, h->d_palette.p, plen * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipMemcpyAsync(h->merge_stats, h->d_scalars.p + 4, sizeof h->merge_stats, hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
     NQ_HIP(h, hipGetLastError());
     if (status) NQ_FAIL(h, NQ_ERR_REFERENCE_THROWS, "ColorUtils.setAlphaComponent: alpha outside 0..255 (the reference throws IllegalArgumentException)");
@@ -512,6 +519,11 @@ int nq_get_params(const nq_handle* h, nq_params* out) {
 int nq_set_params(nq_handle* h, const nq_params* in) {
     if (!h || !in) return NQ_ERR_INVALID;
     h->params = *in; h->params.kind = h->kind;
+    return NQ_OK;
+}
+int nq_get_merge_stats(const nq_handle* h, int64_t* out8) {
+    if (!h || !out8) return NQ_ERR_INVALID;
+    std::memcpy(out8, h->merge_stats, 16 * sizeof(long long));
     return NQ_OK;
 }
 int nq_get_stage_ms(const nq_handle* h, float* out8) {

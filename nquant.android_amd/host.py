@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "nq_abi_version", "nq_create", "nq_destroy", "nq_last_error", "nq_set_stream", "nq_set_tile", "nq_get_params",
     "nq_set_params", "nq_convert", "nq_convert_device", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
-    "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_get_stage_ms",
+    "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_get_stage_ms", "nq_get_merge_stats",
 ]
 
 
@@ -108,6 +108,7 @@ def load_library():
     L.nq_band_histogram_device.argtypes = [vp, vp, i64, vp]
     L.nq_palette_from_histograms_device.argtypes = [vp, vp, i32, i32, vp, C.POINTER(C.c_int32)]
     L.nq_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.nq_get_merge_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     _LIB = L
     return L
 
@@ -188,6 +189,12 @@ class PnnQuantizer:
         a = (C.c_float * 8)()
         self._check(self._L.nq_get_stage_ms(self._h, a))
         return dict(zip(STAGES, list(a)))
+
+    def merge_stats(self):
+        a = (C.c_int64 * 16)()
+        self._check(self._L.nq_get_merge_stats(self._h, a))
+        return dict(zip(["find_nn_calls", "merges", "find_ticks_100MHz", "ctrl_ticks_100MHz", "rebuilds", "overflows", "exact_evals",
+                         "bound_ticks", "exact_ticks", "replay_ticks", "chunks", "chunks_l1", "chunks_l2", "chunks_listed"], list(a)[:14]))
 
     # -- the reference interface --
     def hasAlpha(self):
