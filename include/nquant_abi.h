@@ -82,6 +82,10 @@ int nq_abi_version(void);
 int nq_set_stream(nq_handle* h, void* hip_stream);
 /* Tile of the PARALLEL_TILED decomposition (default 16x16); <=0 restores the default. */
 int nq_set_tile(nq_handle* h, int tile_w, int tile_h);
+/* Tuning switches that never change results.  NQ_OPT_CELL_LISTS (default 1): scan only the per-colour-cell candidate
+ * lists in nearest/closestColorIndex (exact, csrc/nq_lists.inc); 0 = scan the whole palette like the reference. */
+#define NQ_OPT_CELL_LISTS 1
+int nq_set_option(nq_handle* h, int option, int value);
 int nq_get_params(const nq_handle* h, nq_params* out);
 int nq_set_params(nq_handle* h, const nq_params* in);
 

@@ -140,6 +140,9 @@ struct nq_handle {
     DevBuf<short> d_bincache, d_short;
     DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..11] merge stats
     DevBuf<int> live3;                // merge loop: two live lists + position index
+    DevBuf<unsigned char> cell_lists; // closest lists, nearest lists (65536 x 32 each), then their counts (65536 each)
+    DevBuf<float> saliency;           // saliency map of the image being dithered
+    int use_lists = 1;
     DevBuf<float> scan_f;             // merge loop: position-indexed scan arrays (two generations)
     DevBuf<int> scan_i;
     long long merge_stats[16] = {0};
@@ -194,6 +197,33 @@ DevParams dev_params(const nq_handle* h, int K) {
     d.nMaxColors = p.nMaxColors; d.rewriteA0 = p.nMaxColors <= 2 && p.nMaxColors > 0; d.pad = 0;
     d.PR = p.PR; d.PG = p.PG; d.PB = p.PB; d.PA = p.PA; d.ratio = p.ratio; d.weight = p.weight;
     return d;
+}
+
+// candidate lists per colour cell for this palette (nq_lists.inc); empty view = full scans
+int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
+    out->closest = out->closestCount = out->nearest = out->nearestCount = nullptr;
+    if (!h->use_lists || P.K > 256 || P.K < 8) return NQ_OK;
+    const size_t LB = (size_t) 65536 * 32;
+    NQ_HIP(h, h->cell_lists.reserve(2 * LB + 2 * 65536));
+    unsigned char* base = h->cell_lists.p;
+    double wA, wR, wG, wB;
+    if (h->kind == NQ_KIND_LAB) {
+        // err of NQ/PnnLABQuantizer.java:421-445: PR(1-ratio) dr^2 + ... + ratio * sum_i (coeffs[i][c] d)^2
+        double s[3] = {0, 0, 0};
+        for (int i = 0; i < 3; ++i) for (int c = 0; c < 3; ++c) s[c] += (double) kCoeffs[i][c] * (double) kCoeffs[i][c];
+        wR = P.PR * (1 - P.ratio) + P.ratio * s[0]; wG = P.PG * (1 - P.ratio) + P.ratio * s[1]; wB = P.PB * (1 - P.ratio) + P.ratio * s[2];
+        wA = P.hasSemi ? P.PA : 0.0;
+    } else {
+        // NQ/PnnQuantizer.java:325-345
+        double pr = P.PR, pg = P.PG, pb = P.PB, pa = P.PA;
+        if (P.K < 3) pr = pg = pb = pa = 1;
+        wR = pr; wG = pg; wB = pb; wA = P.hasSemi ? pa : 0.0;
+    }
+    const bool nearest = h->kind == NQ_KIND_LAB && P.K > 32 && !P.hasSemi;
+    launch_build_lists(P, h->d_palette.p, wA, wR, wG, wB, nearest, base, base + 2 * LB, base + LB, base + 2 * LB + 65536, h->stream);
+    out->closest = base; out->closestCount = base + 2 * LB;
+    if (nearest) { out->nearest = base + LB; out->nearestCount = base + 2 * LB + 65536; }
+    return NQ_OK;
 }
 
 int get_path(nq_handle* h, int w, int hgt, const uint32_t** out) {
@@ -396,7 +426,10 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
 
     if (mode == NQ_MODE_LOOKUP_ONLY) {
         DevParams P = dev_params(h, K);
-        launch_lookup_only(P, h->d_palette.p, (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
+        nq::ListsView lv;
+        int rcl = prepare_lists(h, P, &lv);
+        if (rcl) return rcl;
+        launch_lookup_only(P, h->d_palette.p, lv, (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
         NQ_HIP(h, hipGetLastError());
         return NQ_OK;
     }
@@ -439,12 +472,20 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         T.path_len[s] = sw[s] * shh[s]; T.shape_w[s] = sw[s]; T.shape_h[s] = shh[s];
     }
     if (sequential) NQ_HIP(h, hipMemsetAsync(h->d_bincache.p, 0xFF, 65536 * sizeof(short), h->stream));
-    rec(h, 5);
-    launch_gilbert(P, G, T, (const int*) d_argb, h->d_palette.p, h->d_bincache.p, (long long) seed, sequential ? 1 : 0,
+    nq::ListsView lv;
+    { int rcl = prepare_lists(h, P, &lv); if (rcl) return rcl; }
+    const float* d_sal = nullptr;
+    if (hasSal) {
+        NQ_HIP(h, h->saliency.reserve((size_t) n));
+        launch_saliency(P, salSubst ? 1 : 0, (const int*) d_argb, n, h->saliency.p, h->stream);
+        d_sal = h->saliency.p;
+    }
+    rec(h, 5);       // stage "palette_fill" ends here: it includes the candidate-list build and the saliency map
+    launch_gilbert(P, G, T, lv, (const int*) d_argb, d_sal, h->d_palette.p, h->d_bincache.p, (long long) seed, sequential ? 1 : 0,
                    h->d_scalars.p, d_out_index, post ? nullptr : (int*) d_out_argb, h->stream);
     rec(h, 6);
     if (post)
-        launch_bluenoise(P, h->d_palette.p, (const int*) d_argb, width, height, blueWeight, (long long) seed, sequential ? 1 : 0,
+        launch_bluenoise(P, h->d_palette.p, lv, (const int*) d_argb, width, height, blueWeight, (long long) seed, sequential ? 1 : 0,
                          h->d_bincache.p, h->d_scalars.p, d_out_index, (int*) d_out_argb, h->stream);
     rec(h, 7);
     NQ_HIP(h, hipGetLastError());
@@ -510,6 +551,11 @@ int nq_set_tile(nq_handle* h, int tile_w, int tile_h) {
     if (tile_w <= 0 || tile_h <= 0) { tile_w = 16; tile_h = 16; }
     h->tile_w = tile_w; h->tile_h = tile_h;
     return NQ_OK;
+}
+int nq_set_option(nq_handle* h, int option, int value) {
+    if (!h) return NQ_ERR_INVALID;
+    if (option == NQ_OPT_CELL_LISTS) { h->use_lists = value != 0; return NQ_OK; }
+    NQ_FAIL(h, NQ_ERR_INVALID, "unknown option %d", option);
 }
 int nq_get_params(const nq_handle* h, nq_params* out) {
     if (!h || !out) return NQ_ERR_INVALID;
@@ -620,7 +666,10 @@ int nq_nearest_index(nq_handle* h, const uint32_t* palette, int K, const uint32_
     NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
     NQ_HIP(h, hipMemcpyAsync(h->d_colors.p, colors, (size_t) M * sizeof(int), hipMemcpyHostToDevice, h->stream));
     DevParams P = dev_params(h, K);
-    launch_nearest_index(P, h->d_palette.p, h->d_colors.p, M, h->d_short.p, h->stream);
+    nq::ListsView lv;
+    rc = prepare_lists(h, P, &lv);
+    if (rc) return rc;
+    launch_nearest_index(P, h->d_palette.p, lv, h->d_colors.p, M, h->d_short.p, h->stream);
     NQ_HIP(h, hipGetLastError());
     NQ_HIP(h, hipMemcpyAsync(out_index, h->d_short.p, (size_t) M * sizeof(short), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -637,7 +686,10 @@ int nq_closest_tuple(nq_handle* h, const uint32_t* palette, int K, const uint32_
     NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
     NQ_HIP(h, hipMemcpyAsync(h->d_colors.p, colors, (size_t) M * sizeof(int), hipMemcpyHostToDevice, h->stream));
     DevParams P = dev_params(h, K);
-    launch_closest_tuple(P, h->d_palette.p, h->d_colors.p, M, h->d_tuple.p, h->stream);
+    nq::ListsView lv;
+    rc = prepare_lists(h, P, &lv);
+    if (rc) return rc;
+    launch_closest_tuple(P, h->d_palette.p, lv, h->d_colors.p, M, h->d_tuple.p, h->stream);
     NQ_HIP(h, hipGetLastError());
     NQ_HIP(h, hipMemcpyAsync(out_closest4, h->d_tuple.p, (size_t) 4 * M * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));

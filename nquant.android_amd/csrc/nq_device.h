@@ -273,6 +273,33 @@ struct PalView {
     const float* B;
 };
 
+// ---- candidate lists per 5-6-5 colour cell (built by nq_lists.inc; exactness argument there) -------------------------
+#define NQ_LIST_CAP 32
+#define NQ_LIST_FULLSCAN 255
+struct CellLists {
+    const unsigned char* closest;        // [65536][NQ_LIST_CAP] palette indices in ascending order, or nullptr (full scans)
+    const unsigned char* closestCount;   // [65536]; NQ_LIST_FULLSCAN = scan the whole palette
+    const unsigned char* nearest;        // same for nearestColorIndex (LAB, K > 32, no semi-transparency), or nullptr
+    const unsigned char* nearestCount;
+};
+struct CellList {                        // one cell's list in four 64-bit words
+    unsigned long long w0, w1, w2, w3;
+    int n;
+    __device__ __forceinline__ int at(int i) const {
+        const unsigned long long w = i < 16 ? (i < 8 ? w0 : w1) : (i < 24 ? w2 : w3);
+        return (int) ((w >> ((i & 7) * 8)) & 0xFF);
+    }
+};
+__device__ __forceinline__ int cell_of(int c) { return (c_red(c) & 0xF8) << 8 | (c_green(c) & 0xFC) << 3 | (c_blue(c) >> 3); }
+__device__ __forceinline__ CellList load_cell_list(const unsigned char* __restrict__ lists, const unsigned char* __restrict__ counts, int cell) {
+    CellList l;
+    l.n = counts[cell];
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(lists + (size_t) cell * NQ_LIST_CAP);
+    const ulonglong2 a = p[0], b = p[1];
+    l.w0 = a.x; l.w1 = a.y; l.w2 = b.x; l.w3 = b.y;
+    return l;
+}
+
 // ---- nearestColorIndex, cache-miss semantics ----------------------------------------------------
 // RGB: NQ/PnnQuantizer.java:276-310
 __device__ __forceinline__ int nearest_rgb(const DevParams& P, const PalView& pal, int c) {
@@ -301,7 +328,7 @@ __device__ __forceinline__ int nearest_rgb(const DevParams& P, const PalView& pa
 }
 
 // LAB: NQ/PnnLABQuantizer.java:337-401
-__device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pal, int c) {
+__device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pal, int c, const CellLists* lists = nullptr) {
     const int K = P.K;
     int k = 0;
     if (c_alpha(c) <= 0xF) c = P.transparentColor;
@@ -335,6 +362,23 @@ __device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pa
             k = i;
         }
     } else if (K > 32) {
+        bool done = false;
+        if (lists && lists->nearest && !(P.hasAlpha && k == 0)) {
+            const CellList cl = load_cell_list(lists->nearest, lists->nearestCount, cell_of(c));
+            if (cl.n != NQ_LIST_FULLSCAN) {
+                for (int t = 0; t < cl.n; ++t) {
+                    const int i = cl.at(t);
+                    double curdist = (double) fabsf(pal.L[i] - lab1.L);
+                    if (curdist > mindist) continue;
+                    curdist += sqrt(sqr((double) (pal.A[i] - lab1.A)) + sqr((double) (pal.B[i] - lab1.B)));
+                    if (curdist > mindist) continue;
+                    mindist = curdist;
+                    k = i;
+                }
+                done = true;
+            }
+        }
+        if (!done)
         for (int i = k; i < K; ++i) {
             double curdist = (double) fabsf(pal.L[i] - lab1.L);     // hasSemi is false here: curdist starts at 0
             if (curdist > mindist) continue;
@@ -367,71 +411,95 @@ __device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pa
     return k;
 }
 
-__device__ __forceinline__ int nearest_any(const DevParams& P, const PalView& pal, int c) {
-    return P.kind == 0 ? nearest_rgb(P, pal, c) : nearest_lab(P, pal, c);
+__device__ __forceinline__ int nearest_any(const DevParams& P, const PalView& pal, int c, const CellLists* lists = nullptr) {
+    return P.kind == 0 ? nearest_rgb(P, pal, c) : nearest_lab(P, pal, c, lists);
 }
 
 // ---- closest[] tuple ------------------------------------------------------------------------------
+// one palette entry of the RGB loop: NQ/PnnQuantizer.java:330-356
+__device__ __forceinline__ void closest_step_rgb(const DevParams& P, const PalView& pal, int k, int ca, int cr, int cg, int cb,
+                                                 double pr, double pg, double pb, double pa, int closest[4]) {
+    const int c2 = pal.argb[k];
+    double err = pr * sqr((double) (c_red(c2) - cr));
+    if (err >= closest[3]) return;
+    err += pg * sqr((double) (c_green(c2) - cg));
+    if (err >= closest[3]) return;
+    err += pb * sqr((double) (c_blue(c2) - cb));
+    if (err >= closest[3]) return;
+    if (P.hasSemi) err += pa * sqr((double) (c_alpha(c2) - ca));
+    if (err < closest[2]) {
+        closest[1] = closest[0]; closest[3] = closest[2];
+        closest[0] = k; closest[2] = j_d2i(err);
+    } else if (err < closest[3]) {
+        closest[1] = k; closest[3] = j_d2i(err);
+    }
+}
 // RGB: NQ/PnnQuantizer.java:322-360
-__device__ __forceinline__ void closest_tuple_rgb(const DevParams& P, const PalView& pal, int c, int closest[4]) {
+__device__ __forceinline__ void closest_tuple_rgb(const DevParams& P, const PalView& pal, int c, int closest[4],
+                                                  const CellLists* lists = nullptr) {
     const int K = P.K;
     closest[0] = closest[1] = 0;
     closest[2] = closest[3] = 2147483647;
     double pr = P.PR, pg = P.PG, pb = P.PB, pa = P.PA;
     if (K < 3) pr = pg = pb = pa = 1;
     const int ca = c_alpha(c), cr = c_red(c), cg = c_green(c), cb = c_blue(c);
-    for (int k = 0; k < K; ++k) {
-        int c2 = pal.argb[k];
-        double err = pr * sqr((double) (c_red(c2) - cr));
-        if (err >= closest[3]) continue;
-        err += pg * sqr((double) (c_green(c2) - cg));
-        if (err >= closest[3]) continue;
-        err += pb * sqr((double) (c_blue(c2) - cb));
-        if (err >= closest[3]) continue;
-        if (P.hasSemi) err += pa * sqr((double) (c_alpha(c2) - ca));
-        if (err < closest[2]) {
-            closest[1] = closest[0]; closest[3] = closest[2];
-            closest[0] = k; closest[2] = j_d2i(err);
-        } else if (err < closest[3]) {
-            closest[1] = k; closest[3] = j_d2i(err);
+    bool done = false;
+    if (lists && lists->closest) {
+        const CellList cl = load_cell_list(lists->closest, lists->closestCount, cell_of(c));
+        if (cl.n != NQ_LIST_FULLSCAN) {
+            for (int t = 0; t < cl.n; ++t) closest_step_rgb(P, pal, cl.at(t), ca, cr, cg, cb, pr, pg, pb, pa, closest);
+            done = true;
         }
     }
+    if (!done) for (int k = 0; k < K; ++k) closest_step_rgb(P, pal, k, ca, cr, cg, cb, pr, pg, pb, pa, closest);
     if (closest[3] == 2147483647) closest[1] = closest[0];
 }
+// one palette entry of the LAB loop: NQ/PnnLABQuantizer.java:419-457
+__device__ __forceinline__ void closest_step_lab(const DevParams& P, const PalView& pal, int k, int ca, int cr, int cg, int cb,
+                                                 double wr, double wg, double wb, double ratio, int closest[4]) {
+    const int c2 = pal.argb[k];
+    const int dr = c_red(c2) - cr, dg = c_green(c2) - cg, db = c_blue(c2) - cb;
+    double err = wr * sqr((double) dr);
+    if (err >= closest[3]) return;
+    err += wg * sqr((double) dg);
+    if (err >= closest[3]) return;
+    err += wb * sqr((double) db);
+    if (err >= closest[3]) return;
+    if (P.hasSemi) err += P.PA * sqr((double) (c_alpha(c2) - ca));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        err += ratio * sqr((double) (k_coeffs[i][0] * dr));
+        if (err >= closest[3]) break;
+        err += ratio * sqr((double) (k_coeffs[i][1] * dg));
+        if (err >= closest[3]) break;
+        err += ratio * sqr((double) (k_coeffs[i][2] * db));
+        if (err >= closest[3]) break;
+    }
+    if (err < closest[2]) {
+        closest[1] = closest[0]; closest[3] = closest[2];
+        closest[0] = k; closest[2] = j_d2i(err);
+    } else if (err < closest[3]) {
+        closest[1] = k; closest[3] = j_d2i(err);
+    }
+}
 // LAB: NQ/PnnLABQuantizer.java:415-461
-__device__ __forceinline__ void closest_tuple_lab(const DevParams& P, const PalView& pal, int c, int closest[4]) {
+__device__ __forceinline__ void closest_tuple_lab(const DevParams& P, const PalView& pal, int c, int closest[4],
+                                                  const CellLists* lists = nullptr) {
     const int K = P.K;
     closest[0] = closest[1] = 0;
     closest[2] = closest[3] = 2147483647;
     const double ratio = P.ratio;
     const double wr = P.PR * (1 - ratio), wg = P.PG * (1 - ratio), wb = P.PB * (1 - ratio);
     const int ca = c_alpha(c), cr = c_red(c), cg = c_green(c), cb = c_blue(c);
-    for (int k = 0; k < K; ++k) {
-        int c2 = pal.argb[k];
-        const int dr = c_red(c2) - cr, dg = c_green(c2) - cg, db = c_blue(c2) - cb;
-        double err = wr * sqr((double) dr);
-        if (err >= closest[3]) continue;
-        err += wg * sqr((double) dg);
-        if (err >= closest[3]) continue;
-        err += wb * sqr((double) db);
-        if (err >= closest[3]) continue;
-        if (P.hasSemi) err += P.PA * sqr((double) (c_alpha(c2) - ca));
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            err += ratio * sqr((double) (k_coeffs[i][0] * dr));
-            if (err >= closest[3]) break;
-            err += ratio * sqr((double) (k_coeffs[i][1] * dg));
-            if (err >= closest[3]) break;
-            err += ratio * sqr((double) (k_coeffs[i][2] * db));
-            if (err >= closest[3]) break;
-        }
-        if (err < closest[2]) {
-            closest[1] = closest[0]; closest[3] = closest[2];
-            closest[0] = k; closest[2] = j_d2i(err);
-        } else if (err < closest[3]) {
-            closest[1] = k; closest[3] = j_d2i(err);
+    bool done = false;
+    if (lists && lists->closest) {
+        const CellList cl = load_cell_list(lists->closest, lists->closestCount, cell_of(c));
+        if (cl.n != NQ_LIST_FULLSCAN) {
+            for (int t = 0; t < cl.n; ++t) closest_step_lab(P, pal, cl.at(t), ca, cr, cg, cb, wr, wg, wb, ratio, closest);
+            done = true;
         }
     }
+    if (!done) for (int k = 0; k < K; ++k) closest_step_lab(P, pal, k, ca, cr, cg, cb, wr, wg, wb, ratio, closest);
     if (closest[3] == 2147483647) closest[1] = closest[0];
 }
 
@@ -444,6 +512,7 @@ struct LookupCtx {
     short* binCache;       // [65536] or nullptr (cache-miss semantics)
     long long rng;         // java.util.Random state of this chain
     int dither;
+    const CellLists* lists; // candidate lists per colour cell, or nullptr
 };
 
 __device__ __forceinline__ int nearest_cached(LookupCtx& cx, int c) {
@@ -452,11 +521,11 @@ __device__ __forceinline__ int nearest_cached(LookupCtx& cx, int c) {
         const int offset = getColorIndex(c, P.hasSemi != 0, P.hasAlpha != 0);
         short got = cx.binCache[offset];
         if (got >= 0) return got;
-        int k = nearest_any(P, cx.pal, c);
+        int k = nearest_any(P, cx.pal, c, cx.lists);
         cx.binCache[offset] = (short) k;
         return k;
     }
-    return nearest_any(P, cx.pal, c);    // a cache keyed by the full colour is transparent: nearest is pure in c
+    return nearest_any(P, cx.pal, c, cx.lists);    // a cache keyed by the full colour is transparent: nearest is pure in c
 }
 
 // RGB closestColorIndex: NQ/PnnQuantizer.java:313-375
@@ -464,7 +533,7 @@ __device__ __forceinline__ int closest_rgb(LookupCtx& cx, int c, int pos) {
     const DevParams& P = *cx.P;
     if (c_alpha(c) <= 0xF) return nearest_cached(cx, c);
     int closest[4];
-    closest_tuple_rgb(P, cx.pal, c, closest);
+    closest_tuple_rgb(P, cx.pal, c, closest, cx.lists);
     const int MAX_ERR = P.K << 2;
     int idx = (pos + 1) % 2;
     if (closest[3] * .67 < (closest[3] - closest[2])) idx = 0;
@@ -477,7 +546,7 @@ __device__ __forceinline__ int closest_lab(LookupCtx& cx, int c) {
     const DevParams& P = *cx.P;
     if (c_alpha(c) <= 0xF) return nearest_cached(cx, c);
     int closest[4];
-    closest_tuple_lab(P, cx.pal, c, closest);
+    closest_tuple_lab(P, cx.pal, c, closest, cx.lists);
     int idx = 1;
     if (closest[2] == 0 ||
         (jr_next_int_bound(cx.rng, 32767) % (int) ((unsigned) closest[3] + (unsigned) closest[2])) <= closest[3])

@@ -43,21 +43,31 @@ struct TileGeom {
 
 void upload_tables(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s);
 
-void launch_nearest_index(const DevParams& P, const int* d_palette, const int* d_colors, int64_t M, short* d_out, hipStream_t s);
-void launch_closest_tuple(const DevParams& P, const int* d_palette, const int* d_colors, int64_t M, int* d_out4, hipStream_t s);
+// candidate lists per 5-6-5 colour cell (nq_lists.inc); null pointers = full palette scans
+struct ListsView {
+    const unsigned char* closest; const unsigned char* closestCount;
+    const unsigned char* nearest; const unsigned char* nearestCount;
+};
+// wA..wB: total weight of da^2, dr^2, dg^2, db^2 in closestColorIndex's err; nearest: also build the nearestColorIndex lists
+void launch_build_lists(const DevParams& P, const int* d_palette, double wA, double wR, double wG, double wB, bool nearest,
+                        unsigned char* d_closest, unsigned char* d_closestCount, unsigned char* d_nearest,
+                        unsigned char* d_nearestCount, hipStream_t s);
+void launch_saliency(const DevParams& P, int salSubst, const int* d_pixels, int64_t N, float* d_out, hipStream_t s);
+
+void launch_nearest_index(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_colors, int64_t M, short* d_out, hipStream_t s);
+void launch_closest_tuple(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_colors, int64_t M, int* d_out4, hipStream_t s);
 // LOOKUP_ONLY: index (+ARGB) of nearestColorIndex(pixel) for every pixel
-void launch_lookup_only(const DevParams& P, const int* d_palette, const int* d_pixels, int64_t N,
+void launch_lookup_only(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int64_t N,
                         unsigned short* d_index, int* d_argb, hipStream_t s);
 
 // GilbertCurve.dither over every tile; writes indices (always) and ARGB (when d_argb != nullptr)
-void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const int* d_pixels,
-                    const int* d_palette, short* d_binCache, long long seed, int sequential, long long* d_rng_state,
-                    unsigned short* d_index, int* d_argb, hipStream_t s);
+void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
+                    const float* d_saliency, const int* d_palette, short* d_binCache, long long seed, int sequential,
+                    long long* d_rng_state, unsigned short* d_index, int* d_argb, hipStream_t s);
 // BlueNoise.dither post-pass (NQ/BlueNoise.java:207-222); in-place on d_index, writes d_argb
-void launch_bluenoise(const DevParams& P, const int* d_palette, const int* d_pixels, int width, int height,
+void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,
                       float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,
                       unsigned short* d_index, int* d_argb, hipStream_t s);
-
 
 // ---- palette build (nq_palette.inc) ----
 struct Bins {

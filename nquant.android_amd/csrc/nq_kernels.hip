@@ -10,6 +10,7 @@ namespace nq {
 __constant__ ConstTables g_tab;
 }
 
+#include "nq_lists.inc"
 #include "nq_dither.inc"
 #include "nq_palette.inc"
 
@@ -35,45 +36,74 @@ static inline int grid_for(int64_t n, int block, int cap = 256 * 8) {
     return (int) g;
 }
 
-void launch_nearest_index(const DevParams& P, const int* d_palette, const int* d_colors, int64_t M, short* d_out, hipStream_t s) {
-    hipLaunchKernelGGL(nearest_index_kernel, dim3(grid_for(M, 256)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
-                       P, d_palette, d_colors, (long long) M, d_out);
-}
-void launch_closest_tuple(const DevParams& P, const int* d_palette, const int* d_colors, int64_t M, int* d_out4, hipStream_t s) {
-    hipLaunchKernelGGL(closest_tuple_kernel, dim3(grid_for(M, 256)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
-                       P, d_palette, d_colors, (long long) M, d_out4);
-}
-void launch_lookup_only(const DevParams& P, const int* d_palette, const int* d_pixels, int64_t N,
-                        unsigned short* d_index, int* d_argb, hipStream_t s) {
-    hipLaunchKernelGGL(lookup_only_kernel, dim3(grid_for(N, 256, 256 * 16)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
-                       P, d_palette, d_pixels, (long long) N, d_index, d_argb);
+static inline CellLists to_lists(const ListsView& v) {
+    CellLists l; l.closest = v.closest; l.closestCount = v.closestCount; l.nearest = v.nearest; l.nearestCount = v.nearestCount;
+    return l;
 }
 
-void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const int* d_pixels,
-                    const int* d_palette, short* d_binCache, long long seed, int sequential, long long* d_rng_state,
-                    unsigned short* d_index, int* d_argb, hipStream_t s) {
+void launch_build_lists(const DevParams& P, const int* d_palette, double wA, double wR, double wG, double wB, bool nearest,
+                        unsigned char* d_closest, unsigned char* d_closestCount, unsigned char* d_nearest,
+                        unsigned char* d_nearestCount, hipStream_t s) {
+    hipLaunchKernelGGL(build_closest_lists_kernel, dim3(65536 / 256), dim3(256), (size_t) P.K * sizeof(int), s, P, d_palette,
+                       wA, wR, wG, wB, d_closest, d_closestCount);
+    if (nearest)
+        hipLaunchKernelGGL(build_nearest_lists_kernel, dim3(65536 / 256), dim3(256), palette_smem_bytes(P.kind, P.K), s, P, d_palette,
+                           P.hasAlpha ? 1 : 0, d_nearest, d_nearestCount);
+}
+
+void launch_saliency(const DevParams& P, int salSubst, const int* d_pixels, int64_t N, float* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(saliency_kernel, dim3(grid_for(N, 256, 256 * 16)), dim3(256), 0, s, P, salSubst, d_pixels, (long long) N, d_out);
+}
+
+void launch_nearest_index(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_colors, int64_t M, short* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(nearest_index_kernel, dim3(grid_for(M, 256)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
+                       P, d_palette, to_lists(lv), d_colors, (long long) M, d_out);
+}
+void launch_closest_tuple(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_colors, int64_t M, int* d_out4, hipStream_t s) {
+    hipLaunchKernelGGL(closest_tuple_kernel, dim3(grid_for(M, 256)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
+                       P, d_palette, to_lists(lv), d_colors, (long long) M, d_out4);
+}
+void launch_lookup_only(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int64_t N,
+                        unsigned short* d_index, int* d_argb, hipStream_t s) {
+    hipLaunchKernelGGL(lookup_only_kernel, dim3(grid_for(N, 256, 256 * 16)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
+                       P, d_palette, to_lists(lv), d_pixels, (long long) N, d_index, d_argb);
+}
+
+template <bool SORTED, int DM>
+static void launch_gilbert_t(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const CellLists& L, const int* d_pixels,
+                             const float* d_saliency, const int* d_palette, short* d_binCache, long long seed, int sequential,
+                             long long* d_rng_state, unsigned short* d_index, int* d_argb, hipStream_t s) {
     const int ntiles = T.tiles_x * T.tiles_y;
     const int block = 64;
     const int grid = (ntiles + block - 1) / block;
-    const size_t smem = palette_smem_bytes(P.kind, P.K);
-    if (G.sortedByYDiff)
-        hipLaunchKernelGGL(gilbert_kernel<true>, dim3(grid), dim3(block), smem, s, P, G, T, d_pixels, d_palette, d_binCache,
-                           seed, sequential, d_rng_state, d_index, d_argb);
-    else
-        hipLaunchKernelGGL(gilbert_kernel<false>, dim3(grid), dim3(block), smem, s, P, G, T, d_pixels, d_palette, d_binCache,
-                           seed, sequential, d_rng_state, d_index, d_argb);
+    hipLaunchKernelGGL((gilbert_kernel<SORTED, DM>), dim3(grid), dim3(block), palette_smem_bytes(P.kind, P.K), s, P, G, T, L, d_pixels,
+                       d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb);
 }
 
-void launch_bluenoise(const DevParams& P, const int* d_palette, const int* d_pixels, int width, int height,
+void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
+                    const float* d_saliency, const int* d_palette, short* d_binCache, long long seed, int sequential,
+                    long long* d_rng_state, unsigned short* d_index, int* d_argb, hipStream_t s) {
+    const CellLists L = to_lists(lv);
+    if (G.sortedByYDiff)
+        launch_gilbert_t<true, 1>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, s);
+    else if (G.DITHER_MAX == 25)
+        launch_gilbert_t<false, 25>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, s);
+    else if (G.DITHER_MAX == 16)
+        launch_gilbert_t<false, 16>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, s);
+    else
+        launch_gilbert_t<false, 9>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, s);
+}
+
+void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,
                       float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,
                       unsigned short* d_index, int* d_argb, hipStream_t s) {
     const size_t smem = palette_smem_bytes(P.kind, P.K);
     if (sequential)
-        hipLaunchKernelGGL(bluenoise_seq_kernel, dim3(1), dim3(64), smem, s, P, d_palette, d_pixels, width, height, weight,
+        hipLaunchKernelGGL(bluenoise_seq_kernel, dim3(1), dim3(64), smem, s, P, d_palette, to_lists(lv), d_pixels, width, height, weight,
                            d_binCache, d_rng_state, d_index, d_argb);
     else
         hipLaunchKernelGGL(bluenoise_kernel, dim3(grid_for((int64_t) width * height, 256, 256 * 16)), dim3(256), smem, s,
-                           P, d_palette, d_pixels, width, height, weight, seed, d_index, d_argb);
+                           P, d_palette, to_lists(lv), d_pixels, width, height, weight, seed, d_index, d_argb);
 }
 
 // ---- palette build launchers ----

@@ -58,10 +58,12 @@ def test_nearest_and_closest_bit_exact(nq, oracle, kind, K, mk, alpha):
     want_tup = oq.closest_tuple(pal, cols)
     gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img)
     gq.set_params(_copy_params(oq.params, nq.Params))
-    got_idx = gq.nearestColorIndex(pal, cols)
-    got_tup = gq.closestTuple(pal, cols)
-    assert (got_idx != want_idx).sum() == 0, "nearest mismatches: %d" % (got_idx != want_idx).sum()
-    assert (got_tup != want_tup).any(axis=1).sum() == 0
+    for use_lists in (1, 0):        # per-colour-cell candidate lists (exact acceleration) on, then the plain full scans
+        gq.set_option(1, use_lists)
+        got_idx = gq.nearestColorIndex(pal, cols)
+        got_tup = gq.closestTuple(pal, cols)
+        assert (got_idx != want_idx).sum() == 0, "nearest mismatches (lists=%d): %d" % (use_lists, (got_idx != want_idx).sum())
+        assert (got_tup != want_tup).any(axis=1).sum() == 0, "closest mismatches (lists=%d)" % use_lists
 
 
 PAL_CASES = [
