@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform"])
-    ap.add_argument("--tile", type=int, default=16)
+    ap.add_argument("--tile", type=int, default=0, help="tile side of the PARALLEL_TILED decomposition (0 = automatic)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="side of the CPU-baseline sample image (0 = skip)")
     args = ap.parse_args()
 
@@ -85,8 +85,11 @@ def main():
     d_in = torch.from_numpy(img.reshape(-1)).cuda()
     d_out = torch.empty(npx, dtype=torch.int32, device="cuda")
     d_idx = torch.empty(npx, dtype=torch.int16, device="cuda")
+    tile = args.tile
+    if tile <= 0:      # the library's automatic rule (nq_set_tile): largest of 16, 8, 4 with >= 131072 tiles
+        tile = next((c for c in (16, 8) if ((W + c - 1) // c) * ((H + c - 1) // c) >= 131072), 4)
     q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), device=local_rank, mode=nq.MODE_PARALLEL_TILED, seed=seed,
-                           tile=(args.tile, args.tile))
+                           tile=(tile, tile))
     q.width, q.height = W, H
     stream = torch.cuda.current_stream()
     q.set_stream(stream.cuda_stream)
@@ -131,12 +134,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dx%d ARGB_8888 %s (seed 3+rank), PnnLABQuantizer.convert(256, dither=true), "
-                                   "PARALLEL_TILED %dx%d tiles, one image per rank per step" % (W, H, args.workload, args.tile, args.tile),
+                                   "PARALLEL_TILED %dx%d tiles, one image per rank per step" % (W, H, args.workload, tile, tile),
                        "palette": int(len(pal)), "maxbins": int(p.maxbins), "parallelism": "1 image per GPU, no collective"},
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "merge_stats": q.merge_stats(),
             "pass_mpixels_s": round(npx / (kernel_ms * 1e-3) / 1e6, 1) if kernel_ms > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "gilbert_kernel<false> (per-pixel nearest/closest colour + error diffusion)",
+            "roofline": {"bound": "hbm", "kernel": "gilbert_kernel<false,25> (per-pixel nearest/closest colour + error diffusion)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * npx, "kernel_ms": round(kernel_ms, 3)},

@@ -80,12 +80,15 @@ const char* nq_last_error(const nq_handle* h);   /* h may be NULL: last error of
 int nq_abi_version(void);
 /* All work of the handle is enqueued on this hipStream_t (NULL = the default stream). */
 int nq_set_stream(nq_handle* h, void* hip_stream);
-/* Tile of the PARALLEL_TILED decomposition (default 16x16); <=0 restores the default. */
+/* Tile of the PARALLEL_TILED decomposition; <= 0 (default) = automatic: the largest of 16x16, 8x8, 4x4 that gives the GPU
+ * at least 131072 independent chains. */
 int nq_set_tile(nq_handle* h, int tile_w, int tile_h);
 /* Tuning switches that never change results.  NQ_OPT_CELL_LISTS (default 1): scan only the per-colour-cell candidate
  * lists in nearest/closestColorIndex (exact, csrc/nq_lists.inc); 0 = scan the whole palette like the reference. */
 #define NQ_OPT_CELL_LISTS 1
 int nq_set_option(nq_handle* h, int option, int value);
+/* Diagnostics: length of every cell's candidate list of the last dither/lookup call (255 = full scan), 65536 bytes each. */
+int nq_get_list_counts(nq_handle* h, uint8_t* closest_counts, uint8_t* nearest_counts);
 int nq_get_params(const nq_handle* h, nq_params* out);
 int nq_set_params(nq_handle* h, const nq_params* in);
 

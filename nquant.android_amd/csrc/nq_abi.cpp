@@ -132,7 +132,7 @@ struct nq_handle {
     hipStream_t stream = nullptr;
     std::string err;
     nq_params params;
-    int tile_w = 16, tile_h = 16;
+    int tile_w = 0, tile_h = 0;       // 0 = automatic (pick_tile)
     float stage_ms[NQ_N_STAGES] = {0};
     // device workspace
     DevBuf<int> d_palette, d_in, d_out_argb, d_colors, d_tuple;
@@ -142,6 +142,8 @@ struct nq_handle {
     DevBuf<int> live3;                // merge loop: two live lists + position index
     DevBuf<unsigned char> cell_lists; // closest lists, nearest lists (65536 x 32 each), then their counts (65536 each)
     DevBuf<float> saliency;           // saliency map of the image being dithered
+    DevBuf<float> cell_box;           // Lab bounding box of every 5-6-5 cell (palette independent, built once)
+    bool cell_box_ready = false;
     int use_lists = 1;
     DevBuf<float> scan_f;             // merge loop: position-indexed scan arrays (two generations)
     DevBuf<int> scan_i;
@@ -194,7 +196,8 @@ DevParams dev_params(const nq_handle* h, int K) {
     d.kind = h->kind; d.K = K; d.hasSemi = p.hasSemiTransparency; d.hasAlpha = p.transparentPixelIndex > -1;
     d.transparentColor = p.transparentColor; d.isNano = p.isNano;
     d.binKeyed = h->kind == NQ_KIND_LAB ? (p.isNano != 0) : !(p.weight > .015);
-    d.nMaxColors = p.nMaxColors; d.rewriteA0 = p.nMaxColors <= 2 && p.nMaxColors > 0; d.pad = 0;
+    d.nMaxColors = p.nMaxColors; d.rewriteA0 = p.nMaxColors <= 2 && p.nMaxColors > 0;
+    { const char* dbg = std::getenv("NQ_DEBUG_FLAGS"); d.pad = dbg ? std::atoi(dbg) : 0; }   // timing experiments only
     d.PR = p.PR; d.PG = p.PG; d.PB = p.PB; d.PA = p.PA; d.ratio = p.ratio; d.weight = p.weight;
     return d;
 }
@@ -220,7 +223,12 @@ int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
         wR = pr; wG = pg; wB = pb; wA = P.hasSemi ? pa : 0.0;
     }
     const bool nearest = h->kind == NQ_KIND_LAB && P.K > 32 && !P.hasSemi;
-    launch_build_lists(P, h->d_palette.p, wA, wR, wG, wB, nearest, base, base + 2 * LB, base + LB, base + 2 * LB + 65536, h->stream);
+    if (nearest && !h->cell_box_ready) {
+        NQ_HIP(h, h->cell_box.reserve((size_t) 65536 * 6));
+        launch_cell_lab_box(h->cell_box.p, h->stream);
+        h->cell_box_ready = true;
+    }
+    launch_build_lists(P, h->d_palette.p, wA, wR, wG, wB, nearest, h->cell_box.p, base, base + 2 * LB, base + LB, base + 2 * LB + 65536, h->stream);
     out->closest = base; out->closestCount = base + 2 * LB;
     if (nearest) { out->nearest = base + LB; out->nearestCount = base + 2 * LB + 65536; }
     return NQ_OK;
@@ -462,7 +470,17 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     std::memset(&T, 0, sizeof T);
     T.width = width; T.height = height;
     if (sequential) { T.tile_w = width; T.tile_h = height; }
-    else { T.tile_w = std::min(h->tile_w, width); T.tile_h = std::min(h->tile_h, height); }
+    else if (h->tile_w > 0 && h->tile_h > 0) { T.tile_w = std::min(h->tile_w, width); T.tile_h = std::min(h->tile_h, height); }
+    else {
+        // automatic: the largest square tile of 16, 8, 4 that still yields >= 2 wavefronts of chains per SIMD (131072 chains);
+        // the tile size does not change the measured dither quality, it only sets how many chains run in parallel
+        int tsz = 4;
+        for (int cand : {16, 8}) {
+            const int64_t tiles = (int64_t) ((width + cand - 1) / cand) * ((height + cand - 1) / cand);
+            if (tiles >= 131072) { tsz = cand; break; }
+        }
+        T.tile_w = std::min(tsz, width); T.tile_h = std::min(tsz, height);
+    }
     T.tiles_x = (width + T.tile_w - 1) / T.tile_w; T.tiles_y = (height + T.tile_h - 1) / T.tile_h;
     const int rw = width - (T.tiles_x - 1) * T.tile_w, rh = height - (T.tiles_y - 1) * T.tile_h;
     const int sw[4] = {T.tile_w, rw, T.tile_w, rw}, shh[4] = {T.tile_h, T.tile_h, rh, rh};
@@ -548,8 +566,16 @@ int nq_set_stream(nq_handle* h, void* hip_stream) {
 }
 int nq_set_tile(nq_handle* h, int tile_w, int tile_h) {
     if (!h) return NQ_ERR_INVALID;
-    if (tile_w <= 0 || tile_h <= 0) { tile_w = 16; tile_h = 16; }
+    if (tile_w <= 0 || tile_h <= 0) { tile_w = 0; tile_h = 0; }
     h->tile_w = tile_w; h->tile_h = tile_h;
+    return NQ_OK;
+}
+int nq_get_list_counts(nq_handle* h, uint8_t* closest_counts, uint8_t* nearest_counts) {
+    if (!h || !closest_counts || !nearest_counts) return NQ_ERR_INVALID;
+    if (!h->cell_lists.p) NQ_FAIL(h, NQ_ERR_INVALID, "no lists built yet");
+    const size_t LB = (size_t) 65536 * 32;
+    NQ_HIP(h, hipMemcpy(closest_counts, h->cell_lists.p + 2 * LB, 65536, hipMemcpyDeviceToHost));
+    NQ_HIP(h, hipMemcpy(nearest_counts, h->cell_lists.p + 2 * LB + 65536, 65536, hipMemcpyDeviceToHost));
     return NQ_OK;
 }
 int nq_set_option(nq_handle* h, int option, int value) {

