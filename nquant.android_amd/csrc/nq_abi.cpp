@@ -380,6 +380,7 @@ int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMax
     NQ_HIP(h, hipMemcpyAsync(h->merge_stats, h->d_scalars.p + 4, sizeof h->merge_stats, hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
     NQ_HIP(h, hipGetLastError());
+    if (h->merge_stats[14]) NQ_FAIL(h, NQ_ERR_HIP, "merge loop aborted by its iteration bound (internal error)");
     if (status) NQ_FAIL(h, NQ_ERR_REFERENCE_THROWS, "ColorUtils.setAlphaComponent: alpha outside 0..255 (the reference throws IllegalArgumentException)");
     p.paletteLength = plen;
     *out_K = plen;
