@@ -24,6 +24,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# One hardware queue per in-flight convert: ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and
+# a short kernel queued behind another stream's long merge kernel in the same hardware queue would wait for it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 
@@ -52,12 +56,15 @@ def cpu_baseline(workload, sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform"])
     ap.add_argument("--tile", type=int, default=0, help="tile side of the PARALLEL_TILED decomposition (0 = automatic)")
-    ap.add_argument("--cpu-sample", type=int, default=512, help="side of the CPU-baseline sample image (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="side of the CPU-baseline sample image (0 = skip)")
+    ap.add_argument("--concurrency", type=int, default=8,
+                    help="independent converts in flight per GPU, each on its own HIP stream and quantizer handle (the merge "
+                         "loop of one convert is a sequential chain on one CU; other converts fill the rest of the chip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,17 +95,45 @@ def main():
     tile = args.tile
     if tile <= 0:      # the library's automatic rule (nq_set_tile): largest of 16, 8, 4 with >= 131072 tiles
         tile = next((c for c in (16, 8) if ((W + c - 1) // c) * ((H + c - 1) // c) >= 131072), 4)
-    q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), device=local_rank, mode=nq.MODE_PARALLEL_TILED, seed=seed,
-                           tile=(tile, tile))
-    q.width, q.height = W, H
-    stream = torch.cuda.current_stream()
-    q.set_stream(stream.cuda_stream)
+    import threading
+    C = max(1, min(args.concurrency, max(args.steps, 1)))
+    lanes = []
+    for c in range(C):
+        st = torch.cuda.Stream()
+        qq = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), device=local_rank, mode=nq.MODE_PARALLEL_TILED, seed=seed,
+                                tile=(tile, tile))
+        qq.width, qq.height = W, H
+        qq.set_stream(st.cuda_stream)
+        lanes.append({"q": qq, "stream": st,
+                      "out": torch.empty(npx, dtype=torch.int32, device="cuda"),
+                      "idx": torch.empty(npx, dtype=torch.int16, device="cuda"),
+                      "stages": {}, "n": 0, "pal": None})
+    q = lanes[0]["q"]
 
-    def step():
-        return q.convert_device(d_in.data_ptr(), 256, True, d_out.data_ptr(), d_idx.data_ptr())
+    def run_lane(ln, nsteps, record):
+        # one host thread per lane: the C ABI blocks only on its own stream (ctypes releases the GIL)
+        for _ in range(nsteps):
+            ln["pal"] = ln["q"].convert_device(d_in.data_ptr(), 256, True, ln["out"].data_ptr(), ln["idx"].data_ptr())
+            if record:
+                for k, v in ln["q"].stage_ms().items():      # HIP events recorded on the launch stream, per stage
+                    ln["stages"][k] = ln["stages"].get(k, 0.0) + v
+                ln["n"] += 1
 
-    for _ in range(args.warmup):
-        step()
+    def run_all(total, record):
+        share = [total // C + (1 if c < total % C else 0) for c in range(C)]
+        th = [threading.Thread(target=run_lane, args=(lanes[c], share[c], record)) for c in range(C) if share[c] > 0]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    torch.cuda.synchronize()
+    # single-convert latency (one stream, nothing else in flight), untimed part of the warm-up
+    t0 = time.perf_counter()
+    run_lane(lanes[0], 1, False)
+    torch.cuda.synchronize()
+    latency_ms = (time.perf_counter() - t0) * 1e3
+    run_all(max(args.warmup, C), False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -106,20 +141,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    stages = {}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pal = step()
-        for k, v in q.stage_ms().items():          # HIP events recorded on the launch stream, per stage
-            stages[k] = stages.get(k, 0.0) + v
+    run_all(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    stages = {k: v / max(args.steps, 1) for k, v in stages.items()}
+    stages = {}
+    nrec = sum(ln["n"] for ln in lanes)
+    for ln in lanes:
+        for k, v in ln["stages"].items():
+            stages[k] = stages.get(k, 0.0) + v
+    stages = {k: v / max(nrec, 1) for k, v in stages.items()}
+    pal = lanes[0]["pal"]
 
     if rank == 0:
         p = q.params
@@ -135,7 +172,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dx%d ARGB_8888 %s (seed 3+rank), PnnLABQuantizer.convert(256, dither=true), "
                                    "PARALLEL_TILED %dx%d tiles, one image per rank per step" % (W, H, args.workload, tile, tile),
-                       "palette": int(len(pal)), "maxbins": int(p.maxbins), "parallelism": "1 image per GPU, no collective"},
+                       "palette": int(len(pal)), "maxbins": int(p.maxbins), "parallelism": "1 image per GPU per step, no collective",
+                       "concurrency": C, "single_convert_latency_ms": round(latency_ms, 2)},
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
             "merge_stats": q.merge_stats(),
             "pass_mpixels_s": round(npx / (kernel_ms * 1e-3) / 1e6, 1) if kernel_ms > 0 else None,
