@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <utility>
@@ -142,6 +143,9 @@ struct nq_handle {
     DevBuf<int> live3;                // merge loop: two live lists + position index
     DevBuf<unsigned char> cell_lists; // closest lists, nearest lists (65536 x 32 each), then their counts (65536 each)
     DevBuf<float> saliency;           // saliency map of the image being dithered
+    DevBuf<unsigned> dk_a, dk_b, di_a, di_b;   // distinct-colour sort scratch
+    DevBuf<unsigned char> dtmp;
+    DevBuf<unsigned long long> dheads;         // {colour, first index} pairs (uint2)
     DevBuf<float> cell_box;           // Lab bounding box of every 5-6-5 cell (palette independent, built once)
     bool cell_box_ready = false;
     int use_lists = 1;
@@ -181,7 +185,7 @@ int use_device(nq_handle* h) {
         }
         upload_tables(gamma, std::exp(1.5), std::exp(1.75), h->stream);
         NQ_HIP(h, hipGetLastError());
-        NQ_HIP(h, h->d_scalars.reserve(32));
+        NQ_HIP(h, h->d_scalars.reserve(40));
         NQ_HIP(h, h->d_ints.reserve(4));
         NQ_HIP(h, h->d_bincache.reserve(65536));
         for (auto& e : h->ev) NQ_HIP(h, hipEventCreate(&e));
@@ -271,6 +275,47 @@ int reserve_palette_ws(nq_handle* h, int64_t n) {
     return NQ_OK;
 }
 
+// number of distinct colours of the image as the histogram sees it (= pixelMap.size() after the histogram); when it is
+// <= cap the colours are returned in first-occurrence order (the insertion order of the reference's HashMap)
+int distinct_colors(nq_handle* h, const uint32_t* d_argb, int64_t n, int64_t cap, int64_t* out_count, std::vector<int32_t>* out_colors) {
+    const bool want = out_colors != nullptr && cap > 0;
+    NQ_HIP(h, h->dk_a.reserve((size_t) n)); NQ_HIP(h, h->dk_b.reserve((size_t) n));
+    if (want) { NQ_HIP(h, h->di_a.reserve((size_t) n)); NQ_HIP(h, h->di_b.reserve((size_t) n)); NQ_HIP(h, h->dheads.reserve((size_t) cap + 1)); }
+    const size_t tb = sort32_temp_bytes(n, want) + 256;
+    NQ_HIP(h, h->dtmp.reserve(tb));
+    unsigned long long* d_out = reinterpret_cast<unsigned long long*>(h->d_scalars.p + 20);
+    launch_distinct((const int*) d_argb, n, h->params.transparentColor, h->dk_a.p, h->dk_b.p, want ? h->di_a.p : nullptr,
+                    want ? h->di_b.p : nullptr, h->dtmp.p, tb, d_out, want ? (void*) h->dheads.p : nullptr, (unsigned) cap, h->stream);
+    unsigned long long res[2] = {0, 0};
+    NQ_HIP(h, hipMemcpyAsync(res, d_out, sizeof res, hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    NQ_HIP(h, hipGetLastError());
+    *out_count = (int64_t) res[0];
+    if (want && (int64_t) res[0] <= cap) {
+        std::vector<unsigned long long> heads(res[0]);
+        NQ_HIP(h, hipMemcpy(heads.data(), h->dheads.p, res[0] * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        // uint2 {colour, index} little endian: low word = colour, high word = first index
+        std::vector<std::pair<uint32_t, uint32_t>> byIndex;
+        for (unsigned long long v : heads) byIndex.emplace_back((uint32_t) (v >> 32), (uint32_t) (v & 0xFFFFFFFFu));
+        std::sort(byIndex.begin(), byIndex.end());
+        out_colors->clear();
+        for (auto& pr : byIndex) out_colors->push_back((int32_t) pr.second);
+    }
+    return NQ_OK;
+}
+
+// keySet() order of java.util.HashMap<Integer, ?> for keys inserted in the given order (OpenJDK 8+; treeified buckets ignored):
+// capacity 16 doubling while size > 0.75 capacity; bucket = (h ^ h >>> 16) & (capacity - 1), h = key; insertion order inside
+std::vector<int32_t> java_hashmap_keyset(const std::vector<int32_t>& inserted) {
+    size_t cap = 16;
+    while ((double) inserted.size() > 0.75 * (double) cap) cap <<= 1;
+    std::vector<std::vector<int32_t>> buckets(cap);
+    for (int32_t k : inserted) { uint32_t hh = (uint32_t) k; hh ^= hh >> 16; buckets[hh & (cap - 1)].push_back(k); }
+    std::vector<int32_t> out;
+    for (auto& b : buckets) for (int32_t k : b) out.push_back(k);
+    return out;
+}
+
 // the scalar part of convert() after the pre-scan (NQ/PnnQuantizer.java:431-436)
 void apply_scan(nq_handle* h, int nMaxColors, int64_t transparent_index, uint32_t transparent_color, int64_t semi_count) {
     nq_params& p = h->params;
@@ -288,7 +333,8 @@ void apply_scan(nq_handle* h, int nMaxColors, int64_t transparent_index, uint32_
 void rec(nq_handle* h, int i) { (void) hipEventRecord(h->ev[i], h->stream); }
 
 // pnnquan after the histogram(s) exist on the device (P4..P10)
-int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMaxColors, uint32_t* out_palette, int32_t* out_K) {
+int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMaxColors, uint32_t* out_palette, int32_t* out_K,
+                      const uint32_t* d_argb = nullptr, int64_t n_pixels = 0) {
     nq_params& p = h->params;
     const int kind = h->kind;
     nq::Bins B = bins_of(h);
@@ -328,9 +374,30 @@ int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMax
             double weightB = nMaxColors / 8000.0;
             if (std::fabs(weightB - weight) < .001) quan_rt = 2;
         }
-        if (maxbins <= nMaxColors)
-            NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "image with <= nMaxColors occupied bins: the pixelMap.size() <= nMaxColors early "
-                    "return (NQ/PnnLABQuantizer.java:193-206, HashMap key order) is not implemented on the GPU yet");
+        if (maxbins <= nMaxColors) {
+            // pixelMap.size() <= nMaxColors is only possible here (every occupied bin holds >= 1 distinct colour)
+            if (!d_argb)
+                NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "<= nMaxColors occupied bins in the multi-band path: the pixelMap.size() <= nMaxColors "
+                        "early return (NQ/PnnLABQuantizer.java:193-206) needs the whole image on one GPU");
+            int64_t cnt = 0;
+            std::vector<int32_t> inserted;
+            int rcd = distinct_colors(h, d_argb, n_pixels, nMaxColors, &cnt, &inserted);
+            if (rcd) return rcd;
+            p.distinctColors = cnt;
+            if (cnt <= nMaxColors) {
+                // NQ/PnnLABQuantizer.java:193-206: palette = pixelMap.keySet() in HashMap order, a transparent colour swapped to slot 0
+                std::vector<int32_t> keys = java_hashmap_keyset(inserted);
+                int k = 0;
+                for (int32_t pixel : keys) {
+                    out_palette[k++] = (uint32_t) pixel;
+                    if (k > 1 && (((uint32_t) pixel) >> 24) == 0) { out_palette[k - 1] = out_palette[0]; out_palette[0] = (uint32_t) pixel; }
+                }
+                p.quan_rt = quan_rt; p.texicab = 0; p.paletteLength = k;
+                *out_K = k;
+                rec(h, 2); rec(h, 3); rec(h, 4); rec(h, 5);
+                return NQ_OK;
+            }
+        }
         if (quan_rt > 0) fn = quan_rt > 1 ? 4 : (nMaxColors < 64 ? 2 : 1);
         texicab = proportional > .0225 && !p.hasSemiTransparency;
         if (p.hasSemiTransparency) p.ratio = .5;
@@ -419,7 +486,7 @@ int pnnquan_device(nq_handle* h, const uint32_t* d_argb, int width, int height, 
     ws.keys_a = h->keys_a.p; ws.keys_b = h->keys_b.p; ws.vals_a = h->vals_a.p; ws.vals_b = h->vals_b.p;
     ws.tmp = h->sort_tmp.p; ws.tmp_bytes = h->sort_tmp.n; ws.seg_start = h->seg.p; ws.seg_end = h->seg.p + 65536;
     launch_histogram(h->kind, (const int*) d_argb, n, hp, ws, h->hist.p, h->stream);
-    return palette_from_hist(h, h->hist.p, 1, nMaxColors, out_palette, out_K);
+    return palette_from_hist(h, h->hist.p, 1, nMaxColors, out_palette, out_K, d_argb, n);
 }
 
 int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, const uint32_t* palette, int K, int dither,
@@ -458,8 +525,12 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         if (sequential)
             NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "REFERENCE_SEQUENTIAL + LAB + dither=false + K>32 needs pixelMap.size() after the gilbert "
                     "pass (NQ/PnnLABQuantizer.java:512); not tracked on the GPU");
-        if (p.distinctColors <= 0)
-            NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "params.distinctColors is required for the LAB BlueNoise weight (NQ/PnnLABQuantizer.java:512)");
+        if (p.distinctColors <= 0) {
+            int64_t cnt = 0;
+            int rcd = distinct_colors(h, d_argb, n, 0, &cnt, nullptr);
+            if (rcd) return rcd;
+            p.distinctColors = cnt;
+        }
         const double delta = sqr(K) / (double) p.distinctColors;
         blueWeight = delta > 0.023 ? 1.0f : (float) (37.013 * delta + 0.906);
     }

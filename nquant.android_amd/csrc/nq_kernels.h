@@ -93,6 +93,9 @@ struct SortWorkspace {
     unsigned *seg_start, *seg_end;   // [65536]
 };
 size_t sort_temp_bytes(int64_t n);
+size_t sort32_temp_bytes(int64_t n, bool pairs);
+void launch_distinct(const int* d_pixels, int64_t n, int transparentColor, unsigned* keys_a, unsigned* keys_b, unsigned* idx_a,
+                     unsigned* idx_b, void* tmp, size_t tmp_bytes, unsigned long long* d_out, void* d_heads, unsigned cap, hipStream_t s);
 void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s);
 void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams& hp, const SortWorkspace& ws,
                       double* d_hist, hipStream_t s);

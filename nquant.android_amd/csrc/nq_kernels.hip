@@ -117,6 +117,31 @@ size_t sort_temp_bytes(int64_t n) {
                                      (const int*) nullptr, (int*) nullptr, (size_t) n, 0, 16, (hipStream_t) 0);
     return bytes;
 }
+size_t sort32_temp_bytes(int64_t n, bool pairs) {
+    size_t bytes = 0;
+    if (pairs)
+        (void) rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned*) nullptr, (unsigned*) nullptr, (const unsigned*) nullptr,
+                                         (unsigned*) nullptr, (size_t) n, 0, 32, (hipStream_t) 0);
+    else
+        (void) rocprim::radix_sort_keys(nullptr, bytes, (const unsigned*) nullptr, (unsigned*) nullptr, (size_t) n, 0, 32, (hipStream_t) 0);
+    return bytes;
+}
+// distinct colours (after the alpha substitution of the histogram).  keys_a/b, idx_a/b: unsigned[n] scratch (idx_* may be null:
+// count only); d_out: unsigned long long[2] {runs, heads written}; d_heads: uint2[cap] {colour, first pixel index} or null
+void launch_distinct(const int* d_pixels, int64_t n, int transparentColor, unsigned* keys_a, unsigned* keys_b, unsigned* idx_a,
+                     unsigned* idx_b, void* tmp, size_t tmp_bytes, unsigned long long* d_out, void* d_heads, unsigned cap, hipStream_t s) {
+    (void) hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(subst_colors_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, transparentColor,
+                       keys_a, idx_a);
+    size_t tb = tmp_bytes;
+    if (idx_a)
+        (void) rocprim::radix_sort_pairs(tmp, tb, (const unsigned*) keys_a, keys_b, (const unsigned*) idx_a, idx_b, (size_t) n, 0, 32, s);
+    else
+        (void) rocprim::radix_sort_keys(tmp, tb, (const unsigned*) keys_a, keys_b, (size_t) n, 0, 32, s);
+    hipLaunchKernelGGL(count_runs_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, keys_b, idx_a ? idx_b : nullptr, (long long) n,
+                       d_out, (uint2*) d_heads, cap);
+}
+
 void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s) {
     (void) hipMemsetAsync(d_scan3, 0xFF, 2 * sizeof(long long), s);      // {-1, -1}
     (void) hipMemsetAsync(d_scan3 + 2, 0, sizeof(long long), s);

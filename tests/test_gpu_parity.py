@@ -182,6 +182,43 @@ def test_convert_end_to_end_tiled(nq, oracle):
     assert ms["total"] > 0
 
 
+FEW_CASES = [
+    (256, lambda: synth.few_colors(64, 64, 71, 100)),                                   # pixelMap.size() <= nMaxColors
+    (256, lambda: synth.with_alpha(synth.few_colors(64, 64, 72, 60), 72)),              # + transparent / semi-transparent
+    (16, lambda: synth.few_colors(48, 48, 73, 12)),
+    (64, lambda: synth.few_colors(64, 48, 74, 64)),                                     # exactly nMaxColors colours
+]
+
+
+@pytest.mark.parametrize("K,mk", FEW_CASES)
+def test_lab_few_colours_early_return(nq, oracle, K, mk):
+    """NQ/PnnLABQuantizer.java:193-206: palette = the image's distinct colours in java.util.HashMap key order."""
+    img = mk()
+    seed = 3
+    oq, want = _oracle_palette(oracle, 1, img, K)
+    oq.set_seed(seed)
+    want_argb, want_idx = oq.dither(want, True, tile=(16, 16))
+    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=seed, tile=(16, 16))
+    out = gq.convert(K, True)
+    assert len(out.palette) == len(want) and (out.palette == want).all()
+    assert gq.params.distinctColors == oq.params.distinctColors
+    assert (out.index.astype(np.int32) == want_idx).all() and (out.argb == want_argb).all()
+
+
+def test_lab_no_dither_convert_computes_distinct_colours(nq, oracle):
+    """convert(256, false): the BlueNoise weight needs pixelMap.size() (NQ/PnnLABQuantizer.java:512), counted on the GPU."""
+    img = synth.gradient_noise(112, 96, 81)
+    seed = 4
+    oq, pal = _oracle_palette(oracle, 1, img, 256)
+    oq.set_seed(seed)
+    want_argb, want_idx = oq.dither(pal, False, tile=(16, 16))
+    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=seed, tile=(16, 16))
+    out = gq.convert(256, False)
+    assert (out.palette == pal).all()
+    assert gq.params.distinctColors == oq.params.distinctColors
+    assert (out.index.astype(np.int32) == want_idx).all() and (out.argb == want_argb).all()
+
+
 def test_tiled_deviation_from_sequential_reference_is_small(nq, oracle):
     """PARALLEL_TILED vs the sequential reference semantics: per-pixel CIE76 deltaE against the source must not be
     worse than the sequential oracle's by more than 10 %, and the two results stay close on average."""
