@@ -80,8 +80,15 @@ static void launch_gilbert_t(const DevParams& P, const GilbertConsts& G, const T
     const int ntiles = T.tiles_x * T.tiles_y;
     const int block = 64;
     const int grid = (ntiles + block - 1) / block;
-    hipLaunchKernelGGL((gilbert_kernel<SORTED, DM>), dim3(grid), dim3(block), palette_tables_smem_bytes(P.kind, P.K), s, P, G, T, L, d_pixels,
-                       d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb);
+    const size_t base = palette_tables_smem_bytes(P.kind, P.K);
+    const int tilepx = T.tile_w * T.tile_h;
+    const bool stage = P.K <= 256 && tilepx <= 256 && !sequential;
+    if (stage)
+        hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, true>), dim3(grid), dim3(block), base + (size_t) 64 * tilepx, s, P, G, T, L, d_pixels,
+                           d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb);
+    else
+        hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, false>), dim3(grid), dim3(block), base, s, P, G, T, L, d_pixels,
+                           d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb);
 }
 
 void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
