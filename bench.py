@@ -26,12 +26,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 # One hardware queue per in-flight convert: ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and
 # a short kernel queued behind another stream's long merge kernel in the same hardware queue would wait for it.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "64")
 
 import numpy as np
 import torch
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "gilbert_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command
 BYTES_PER_PIXEL = 8             # 4 B ARGB read + 4 B ARGB write
 
 
@@ -53,16 +54,30 @@ def cpu_baseline(workload, sample):
             "nproc": os.cpu_count()}
 
 
+def measured_traffic(w, h):
+    """HBM bytes per gilbert_kernel launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    `bench.py --steps 1 --concurrency 1`, summaries under profiles/): 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests as 64 B; confirmed here on prescan_kernel: 32 787 KB for a 64 MiB read).
+    Only valid for the image size it was measured on."""
+    try:
+        t = json.load(open(TRAFFIC_FILE))
+        if t.get("width") == w and t.get("height") == h:
+            return int(2 * t["FETCH_SIZE_KB"] * 1024 + t["WRITE_SIZE_KB"] * 1024)
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform"])
     ap.add_argument("--tile", type=int, default=0, help="tile side of the PARALLEL_TILED decomposition (0 = automatic)")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="side of the CPU-baseline sample image (0 = skip)")
-    ap.add_argument("--concurrency", type=int, default=8,
+    ap.add_argument("--concurrency", type=int, default=24,
                     help="independent converts in flight per GPU, each on its own HIP stream and quantizer handle (the merge "
                          "loop of one convert is a sequential chain on one CU; other converts fill the rest of the chip)")
     args = ap.parse_args()
@@ -179,7 +194,7 @@ def main():
             "pass_mpixels_s": round(npx / (kernel_ms * 1e-3) / 1e6, 1) if kernel_ms > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "gilbert_kernel<false,25> (per-pixel nearest/closest colour + error diffusion)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": measured_traffic(W, H),
                          "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * npx, "kernel_ms": round(kernel_ms, 3)},
         }
         if world == 1 and args.cpu_sample > 0:
