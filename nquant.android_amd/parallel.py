@@ -29,10 +29,7 @@ def band_bounds(height, rank, world):
 def reduce_scan(scan3, group=None):
     """scan3 = int64[3] {max global index of an alpha==0 pixel or -1, its colour, count of semi-transparent pixels} of this
     band.  Returns the image-wide triple: the LAST transparent pixel wins (NQ/PnnQuantizer.java:419-422), counts add."""
-    world = dist.get_world_size(group)
-    gathered = [torch.empty_like(scan3) for _ in range(world)]
-    dist.all_gather(gathered, scan3, group=group)
-    allv = torch.stack(gathered).cpu()
+    allv = _gather_small(scan3, group)
     winner = int(torch.argmax(allv[:, 0]))
     idx = int(allv[winner, 0])
     color = int(allv[winner, 1]) if idx >= 0 else -1
@@ -43,10 +40,23 @@ def reduce_scan(scan3, group=None):
 def gather_histograms(hist, group=None):
     """hist = f64[65536*5] partial of this band -> f64[world, 65536*5] in band (= rank) order on every rank."""
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(hist.shape), dtype=hist.dtype, device=hist.device)
-    dist.all_gather_into_tensor(out, hist.contiguous(), group=group) if hasattr(dist, "all_gather_into_tensor") and hist.is_cuda \
-        else dist.all_gather(list(out.unbind(0)), hist.contiguous(), group=group)
-    return out
+    on_gpu = hist.is_cuda
+    backend = dist.get_backend(group)
+    src = hist.contiguous()
+    if on_gpu and backend != "nccl":            # gloo in the tests: stage through the host
+        src = src.cpu()
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    out = torch.stack(parts)
+    return out.to(hist.device) if on_gpu else out
+
+
+def _gather_small(t, group=None):
+    world = dist.get_world_size(group)
+    src = t.cpu() if (t.is_cuda and dist.get_backend(group) != "nccl") else t
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    return torch.stack(parts).cpu()
 
 
 def max_over_ranks(seconds, device="cpu", group=None):

@@ -265,3 +265,35 @@ def test_full_size_properties_4096(nq):
     def ch(a, s): return ((a.view(np.uint32) >> s) & 0xFF).astype(np.float64)
     err = np.mean([np.abs(ch(out, s) - ch(img.reshape(-1), s)).mean() for s in (0, 8, 16)])
     assert err < 12.0, err
+
+
+def test_banded_pipeline_single_rank_equals_convert(nq, oracle, tmp_path):
+    """The multi-GPU band pipeline (band scan -> reduce -> band histogram -> gather -> palette from histograms -> dither of the
+    band, nquant.android_amd.parallel.convert_banded) with ONE rank and one band must equal the plain convert; the collectives
+    run through torch.distributed (gloo here, RCCL on a multi-GPU node)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from nquant.android_amd import parallel
+    img = synth.with_alpha(synth.gradient_noise(96, 80, 91), 91)
+    seed = 6
+    oq, pal = _oracle_palette(oracle, 1, img, 256)
+    oq.set_seed(seed)
+    want_argb, want_idx = oq.dither(pal, True, tile=(16, 16))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        H, W = img.shape
+        d_band = torch.from_numpy(img.reshape(-1)).cuda()
+        d_out = torch.empty(W * H, dtype=torch.int32, device="cuda")
+        d_idx = torch.empty(W * H, dtype=torch.int16, device="cuda")
+        q = nq.PnnLABQuantizer(img, mode=TILED, seed=seed, tile=(16, 16))
+        got_pal = parallel.convert_banded(q, d_band, W, H, 0, 256, True, d_out, d_idx)
+        torch.cuda.synchronize()
+        assert (got_pal == pal).all()
+        assert (d_idx.cpu().numpy().view(np.uint16).astype(np.int32).reshape(H, W) == want_idx).all()
+        assert (d_out.cpu().numpy().reshape(H, W) == want_argb).all()
+    finally:
+        dist.destroy_process_group()
