@@ -297,3 +297,37 @@ def test_banded_pipeline_single_rank_equals_convert(nq, oracle, tmp_path):
         assert (d_out.cpu().numpy().reshape(H, W) == want_argb).all()
     finally:
         dist.destroy_process_group()
+
+
+def test_two_band_rgb_palette_equals_whole_image(nq, oracle):
+    """BASELINE cfg 5 semantics on one GPU: the image cut into two row bands, pre-scan partials reduced (last transparent pixel
+    wins, counts add), per-band histograms combined in band order.  RGB sums are integers, so the palette must equal the
+    oracle's whole-image palette bit for bit."""
+    import ctypes as C
+    import torch
+    img = synth.with_alpha(synth.gradient_noise(96, 64, 93), 93)
+    K = 64
+    oq, want = _oracle_palette(oracle, 0, img, K)
+    H, W = img.shape
+    q = nq.PnnQuantizer(img)
+    L = q._L
+    bands = [(0, 37), (37, H)]
+    d_img = torch.from_numpy(img.reshape(-1)).cuda()
+    scans = []
+    for (y0, y1) in bands:
+        s3 = torch.empty(3, dtype=torch.int64, device="cuda")
+        q._check(L.nq_band_scan_device(q._h, C.c_void_p(d_img[y0 * W:].data_ptr()), (y1 - y0) * W, y0 * W, K, C.c_void_p(s3.data_ptr())))
+        torch.cuda.synchronize()
+        scans.append(s3.cpu().numpy())
+    win = max(scans, key=lambda s: s[0])
+    q._check(L.nq_set_scan(q._h, K, int(win[0]), C.c_uint32(int(win[1]) & 0xFFFFFFFF), int(sum(s[2] for s in scans))))
+    hists = torch.empty((2, 65536 * 5), dtype=torch.float64, device="cuda")
+    for b, (y0, y1) in enumerate(bands):
+        q._check(L.nq_band_histogram_device(q._h, C.c_void_p(d_img[y0 * W:].data_ptr()), (y1 - y0) * W, C.c_void_p(hists[b].data_ptr())))
+    pal = np.zeros(K, np.int32)
+    k = C.c_int32(0)
+    q._check(L.nq_palette_from_histograms_device(q._h, C.c_void_p(hists.data_ptr()), 2, K, pal.ctypes.data, C.byref(k)))
+    assert k.value == len(want) and (pal[:k.value] == want).all()
+    op, gp = oq.params, q.params
+    assert (op.transparentPixelIndex, op.transparentColor, op.hasSemiTransparency, op.maxbins) == \
+           (gp.transparentPixelIndex, gp.transparentColor, gp.hasSemiTransparency, gp.maxbins)
