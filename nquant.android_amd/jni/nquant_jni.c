@@ -1,0 +1,51 @@
+/*
+ * nquant_jni.c -- JNI shim between the reference's Java API and libnquant_hip.so (include/nquant_abi.h).
+ * NOT compiled in the build image (no JDK / jni.h there); build on a box with a JDK:
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include nquant_jni.c \
+ *       -L.. -lnquant_hip -o libnquant_jni.so
+ * Java side: ../java/com/android/nQuant/PnnQuantizer.java, PnnLABQuantizer.java (same class names, constructor and
+ * convert()/hasAlpha() signatures as the reference: NQ/PnnQuantizer.java:35,409,458; NQ/PnnLABQuantizer.java:24).
+ */
+#include <jni.h>
+#include <stdint.h>
+#include "nquant_abi.h"
+
+static void throw_rt(JNIEnv* env, const char* msg) {
+    (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/RuntimeException"), msg ? msg : "nquant error");
+}
+
+JNIEXPORT jlong JNICALL Java_com_android_nQuant_PnnQuantizer_nqCreate(JNIEnv* env, jclass c, jint kind, jint device) {
+    nq_handle* h = NULL;
+    if (nq_create(kind, device, &h) != NQ_OK) { throw_rt(env, nq_last_error(NULL)); return 0; }
+    return (jlong) (intptr_t) h;
+}
+
+JNIEXPORT void JNICALL Java_com_android_nQuant_PnnQuantizer_nqDestroy(JNIEnv* env, jclass c, jlong h) {
+    nq_destroy((nq_handle*) (intptr_t) h);
+}
+
+/* returns the palette; fills outArgb (w*h) and, when non-null, outIndex (w*h) */
+JNIEXPORT jintArray JNICALL Java_com_android_nQuant_PnnQuantizer_nqConvert(JNIEnv* env, jclass c, jlong hh, jintArray argb,
+        jint w, jint hgt, jint nMaxColors, jboolean dither, jlong seed, jint mode, jintArray outArgb, jshortArray outIndex) {
+    nq_handle* h = (nq_handle*) (intptr_t) hh;
+    static uint32_t palette[32768];
+    int32_t K = 0;
+    jint* in = (*env)->GetPrimitiveArrayCritical(env, argb, NULL);         /* the reference's int[] pixels, no copy */
+    jint* out = (*env)->GetPrimitiveArrayCritical(env, outArgb, NULL);
+    jshort* idx = outIndex ? (*env)->GetPrimitiveArrayCritical(env, outIndex, NULL) : NULL;
+    int rc = nq_convert(h, (const uint32_t*) in, w, hgt, nMaxColors, dither ? 1 : 0, seed, mode,
+                        (uint32_t*) out, (uint16_t*) idx, palette, &K);
+    if (idx) (*env)->ReleasePrimitiveArrayCritical(env, outIndex, idx, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, outArgb, out, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, argb, in, JNI_ABORT);           /* the input is never modified */
+    if (rc != NQ_OK) { throw_rt(env, nq_last_error(h)); return NULL; }        /* convert() `throws Exception` */
+    jintArray pal = (*env)->NewIntArray(env, K);
+    (*env)->SetIntArrayRegion(env, pal, 0, K, (const jint*) palette);
+    return pal;
+}
+
+JNIEXPORT jboolean JNICALL Java_com_android_nQuant_PnnQuantizer_nqHasAlpha(JNIEnv* env, jclass c, jlong hh) {
+    nq_params p;
+    if (nq_get_params((nq_handle*) (intptr_t) hh, &p) != NQ_OK) return JNI_FALSE;
+    return p.transparentPixelIndex > -1 ? JNI_TRUE : JNI_FALSE;               /* NQ/PnnQuantizer.java:458-460 */
+}
