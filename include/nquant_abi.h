@@ -106,6 +106,19 @@ int nq_convert_device(nq_handle* h, const uint32_t* d_argb, int width, int heigh
                       int64_t rng_seed, int mode,
                       uint32_t* d_out_argb, uint16_t* d_out_index, uint32_t* out_palette, int32_t* out_K);
 
+/* ---- convert() of n quantizer objects in one call (the reference app converts one file per executor task,
+ *      app/src/main/java/nQuant/android/MainActivity.java:190-214; a service converting many images hands them over
+ *      together).  Results are identical to n separate nq_convert_device calls.  The merge loop of one image is a
+ *      sequential chain that occupies one CU; here the n merge loops run side by side in ONE launch (one workgroup
+ *      each), the other stages run image after image on the first handle's stream and share its per-pixel scratch.
+ *      hs[i] are distinct handles on one device (mixing kinds is allowed); all pointer arrays are host arrays of n
+ *      device pointers; out_palettes[i * palette_stride ...] / out_K[i] receive palette i
+ *      (palette_stride >= max(nMaxColors, 2)); d_out_index may be NULL. ---- */
+int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* d_argb, const int32_t* widths,
+                            const int32_t* heights, int nMaxColors, int dither, const int64_t* rng_seeds, int mode,
+                            uint32_t* const* d_out_argb, uint16_t* const* d_out_index,
+                            uint32_t* out_palettes, int32_t palette_stride, int32_t* out_K);
+
 /* ---- Integer[] pnnquan(int[] pixels, int nMaxColors) incl. the alpha pre-scan of convert()
  *      (NQ/PnnQuantizer.java:410-436,134-267; NQ/PnnLABQuantizer.java:131-327) ---- */
 int nq_pnnquan(nq_handle* h, const uint32_t* argb, int width, int height, int nMaxColors,

@@ -128,19 +128,13 @@ std::vector<uint32_t> gilbert_path(int w, int h) {
 
 } // namespace
 
-struct nq_handle {
-    int kind = 0, device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    nq_params params;
-    int tile_w = 0, tile_h = 0;       // 0 = automatic (pick_tile)
-    float stage_ms[NQ_N_STAGES] = {0};
-    // device workspace
-    DevBuf<int> d_palette, d_in, d_out_argb, d_colors, d_tuple;
-    DevBuf<unsigned short> d_out_index, keys_a, keys_b;
-    DevBuf<short> d_bincache, d_short;
-    DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..11] merge stats
-    DevBuf<int> live3;                // merge loop: two live lists + position index
+// per-pixel scratch that lives only inside one stage of one image: the handles of a batch share the first handle's
+struct Scratch {
+    DevBuf<unsigned short> keys_a, keys_b;
+    DevBuf<int> vals_a, vals_b;
+    DevBuf<unsigned char> sort_tmp;
+    DevBuf<unsigned> seg;             // start[65536], end[65536]
+    DevBuf<double> hist;              // [65536][5]
     DevBuf<unsigned char> cell_lists; // closest lists, nearest lists (65536 x 32 each), then their counts (65536 each)
     DevBuf<float> saliency;           // saliency map of the image being dithered
     DevBuf<unsigned> dk_a, dk_b, di_a, di_b;   // distinct-colour sort scratch
@@ -148,15 +142,30 @@ struct nq_handle {
     DevBuf<unsigned long long> dheads;         // {colour, first index} pairs (uint2)
     DevBuf<float> cell_box;           // Lab bounding box of every 5-6-5 cell (palette independent, built once)
     bool cell_box_ready = false;
+};
+
+struct nq_handle {
+    int kind = 0, device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    nq_params params;
+    int tile_w = 0, tile_h = 0;       // 0 = automatic (pick_tile)
+    float stage_ms[NQ_N_STAGES] = {0};
+    Scratch own;
+    Scratch* sc = &own;
+    // device workspace
+    DevBuf<int> d_palette, d_in, d_out_argb, d_colors, d_tuple;
+    DevBuf<unsigned short> d_out_index;
+    DevBuf<short> d_bincache, d_short;
+    DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..19] merge stats, [20..21] distinct-colour result
+    DevBuf<int> live3;                // merge loop: two live lists + position index
     int use_lists = 1;
     DevBuf<float> scan_f;             // merge loop: position-indexed scan arrays (two generations)
     DevBuf<int> scan_i;
+    DevBuf<nq::MergeJob> d_jobs;      // merge jobs of the current call (1, or the whole batch on the first handle)
     long long merge_stats[16] = {0};
     DevBuf<int> d_ints;               // [0] maxbins, [1] status
-    DevBuf<int> vals_a, vals_b, heap;
-    DevBuf<unsigned char> sort_tmp;
-    DevBuf<unsigned> seg;             // start[65536], end[65536]
-    DevBuf<double> hist;              // [65536][5]
+    DevBuf<int> heap;
     DevBuf<float> binf;               // f[4], cnt, err : 6 x 65536
     DevBuf<double> bind;              // d[4] : 4 x 65536
     DevBuf<int> bini;                 // nn, tm, mtm : 3 x 65536
@@ -211,8 +220,8 @@ int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
     out->closest = out->closestCount = out->nearest = out->nearestCount = nullptr;
     if (!h->use_lists || P.K > 256 || P.K < 8) return NQ_OK;
     const size_t LB = (size_t) 65536 * 32;
-    NQ_HIP(h, h->cell_lists.reserve(2 * LB + 2 * 65536));
-    unsigned char* base = h->cell_lists.p;
+    NQ_HIP(h, h->sc->cell_lists.reserve(2 * LB + 2 * 65536));
+    unsigned char* base = h->sc->cell_lists.p;
     double wA, wR, wG, wB;
     if (h->kind == NQ_KIND_LAB) {
         // err of NQ/PnnLABQuantizer.java:421-445: PR(1-ratio) dr^2 + ... + ratio * sum_i (coeffs[i][c] d)^2
@@ -227,12 +236,12 @@ int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
         wR = pr; wG = pg; wB = pb; wA = P.hasSemi ? pa : 0.0;
     }
     const bool nearest = h->kind == NQ_KIND_LAB && P.K > 32 && !P.hasSemi;
-    if (nearest && !h->cell_box_ready) {
-        NQ_HIP(h, h->cell_box.reserve((size_t) 65536 * 6));
-        launch_cell_lab_box(h->cell_box.p, h->stream);
-        h->cell_box_ready = true;
+    if (nearest && !h->sc->cell_box_ready) {
+        NQ_HIP(h, h->sc->cell_box.reserve((size_t) 65536 * 6));
+        launch_cell_lab_box(h->sc->cell_box.p, h->stream);
+        h->sc->cell_box_ready = true;
     }
-    launch_build_lists(P, h->d_palette.p, wA, wR, wG, wB, nearest, h->cell_box.p, base, base + 2 * LB, base + LB, base + 2 * LB + 65536, h->stream);
+    launch_build_lists(P, h->d_palette.p, wA, wR, wG, wB, nearest, h->sc->cell_box.p, base, base + 2 * LB, base + LB, base + 2 * LB + 65536, h->stream);
     out->closest = base; out->closestCount = base + 2 * LB;
     if (nearest) { out->nearest = base + LB; out->nearestCount = base + 2 * LB + 65536; }
     return NQ_OK;
@@ -263,11 +272,11 @@ nq::Bins bins_of(nq_handle* h) {
 }
 
 int reserve_palette_ws(nq_handle* h, int64_t n) {
-    NQ_HIP(h, h->keys_a.reserve((size_t) n)); NQ_HIP(h, h->keys_b.reserve((size_t) n));
-    NQ_HIP(h, h->vals_a.reserve((size_t) n)); NQ_HIP(h, h->vals_b.reserve((size_t) n));
-    NQ_HIP(h, h->sort_tmp.reserve(sort_temp_bytes(n) + 256));
-    NQ_HIP(h, h->seg.reserve(2 * 65536));
-    NQ_HIP(h, h->hist.reserve((size_t) 65536 * 5));
+    NQ_HIP(h, h->sc->keys_a.reserve((size_t) n)); NQ_HIP(h, h->sc->keys_b.reserve((size_t) n));
+    NQ_HIP(h, h->sc->vals_a.reserve((size_t) n)); NQ_HIP(h, h->sc->vals_b.reserve((size_t) n));
+    NQ_HIP(h, h->sc->sort_tmp.reserve(sort_temp_bytes(n) + 256));
+    NQ_HIP(h, h->sc->seg.reserve(2 * 65536));
+    NQ_HIP(h, h->sc->hist.reserve((size_t) 65536 * 5));
     NQ_HIP(h, h->binf.reserve((size_t) 6 * 65536)); NQ_HIP(h, h->bind.reserve((size_t) 4 * 65536));
     NQ_HIP(h, h->bini.reserve((size_t) 3 * 65536)); NQ_HIP(h, h->heap.reserve(2 * (65536 + 2)));
     NQ_HIP(h, h->live3.reserve((size_t) 3 * 65536));
@@ -279,13 +288,13 @@ int reserve_palette_ws(nq_handle* h, int64_t n) {
 // <= cap the colours are returned in first-occurrence order (the insertion order of the reference's HashMap)
 int distinct_colors(nq_handle* h, const uint32_t* d_argb, int64_t n, int64_t cap, int64_t* out_count, std::vector<int32_t>* out_colors) {
     const bool want = out_colors != nullptr && cap > 0;
-    NQ_HIP(h, h->dk_a.reserve((size_t) n)); NQ_HIP(h, h->dk_b.reserve((size_t) n));
-    if (want) { NQ_HIP(h, h->di_a.reserve((size_t) n)); NQ_HIP(h, h->di_b.reserve((size_t) n)); NQ_HIP(h, h->dheads.reserve((size_t) cap + 1)); }
+    NQ_HIP(h, h->sc->dk_a.reserve((size_t) n)); NQ_HIP(h, h->sc->dk_b.reserve((size_t) n));
+    if (want) { NQ_HIP(h, h->sc->di_a.reserve((size_t) n)); NQ_HIP(h, h->sc->di_b.reserve((size_t) n)); NQ_HIP(h, h->sc->dheads.reserve((size_t) cap + 1)); }
     const size_t tb = sort32_temp_bytes(n, want) + 256;
-    NQ_HIP(h, h->dtmp.reserve(tb));
+    NQ_HIP(h, h->sc->dtmp.reserve(tb));
     unsigned long long* d_out = reinterpret_cast<unsigned long long*>(h->d_scalars.p + 20);
-    launch_distinct((const int*) d_argb, n, h->params.transparentColor, h->dk_a.p, h->dk_b.p, want ? h->di_a.p : nullptr,
-                    want ? h->di_b.p : nullptr, h->dtmp.p, tb, d_out, want ? (void*) h->dheads.p : nullptr, (unsigned) cap, h->stream);
+    launch_distinct((const int*) d_argb, n, h->params.transparentColor, h->sc->dk_a.p, h->sc->dk_b.p, want ? h->sc->di_a.p : nullptr,
+                    want ? h->sc->di_b.p : nullptr, h->sc->dtmp.p, tb, d_out, want ? (void*) h->sc->dheads.p : nullptr, (unsigned) cap, h->stream);
     unsigned long long res[2] = {0, 0};
     NQ_HIP(h, hipMemcpyAsync(res, d_out, sizeof res, hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -293,7 +302,7 @@ int distinct_colors(nq_handle* h, const uint32_t* d_argb, int64_t n, int64_t cap
     *out_count = (int64_t) res[0];
     if (want && (int64_t) res[0] <= cap) {
         std::vector<unsigned long long> heads(res[0]);
-        NQ_HIP(h, hipMemcpy(heads.data(), h->dheads.p, res[0] * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        NQ_HIP(h, hipMemcpy(heads.data(), h->sc->dheads.p, res[0] * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         // uint2 {colour, index} little endian: low word = colour, high word = first index
         std::vector<std::pair<uint32_t, uint32_t>> byIndex;
         for (unsigned long long v : heads) byIndex.emplace_back((uint32_t) (v >> 32), (uint32_t) (v & 0xFFFFFFFFu));
@@ -332,9 +341,17 @@ void apply_scan(nq_handle* h, int nMaxColors, int64_t transparent_index, uint32_
 
 void rec(nq_handle* h, int i) { (void) hipEventRecord(h->ev[i], h->stream); }
 
-// pnnquan after the histogram(s) exist on the device (P4..P10)
-int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMaxColors, uint32_t* out_palette, int32_t* out_K,
-                      const uint32_t* d_argb = nullptr, int64_t n_pixels = 0) {
+// what palette_prepare leaves for the merge launch and palette_finish; merge == false: the palette is already final
+struct PaletteJob {
+    bool merge = false;
+    nq::MergeJob mj;
+    int plen = 0;
+};
+
+// pnnquan after the histogram(s) exist on the device, up to the initial find_nn pass (P4..P8)
+int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxColors, uint32_t* out_palette, int32_t* out_K,
+                    const uint32_t* d_argb, int64_t n_pixels, PaletteJob* job) {
+    job->merge = false;
     nq_params& p = h->params;
     const int kind = h->kind;
     nq::Bins B = bins_of(h);
@@ -434,12 +451,40 @@ int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMax
         }
     }
     const int extbins = maxbins - nMaxColors;
-    launch_merge(np, B, maxbins, extbins, h->heap.p, h->live3.p, h->scan_f.p, h->scan_i.p, h->d_scalars.p + 4, h->stream);
-    rec(h, 4);
-    const int plen = extbins > 0 ? nMaxColors : maxbins;
+    job->merge = true;
+    job->mj.np = np; job->mj.B = B; job->mj.maxbins = maxbins; job->mj.extbins = extbins;
+    job->mj.heap = h->heap.p; job->mj.live3 = h->live3.p; job->mj.scan_f = h->scan_f.p; job->mj.scan_i = h->scan_i.p;
+    job->mj.stats = h->d_scalars.p + 4;
+    job->plen = extbins > 0 ? nMaxColors : maxbins;
+    return NQ_OK;
+}
+
+// the merge loops (P9) of n prepared images in one launch per kind, on the stream of `owner`
+int merge_launch(nq_handle* owner, const PaletteJob* const* jobs, int n) {
+    std::vector<nq::MergeJob> host;
+    int n_lab = 0;
+    for (int pass = 1; pass >= 0; --pass) {                 // LAB jobs first, then RGB
+        for (int i = 0; i < n; ++i)
+            if (jobs[i]->merge && jobs[i]->mj.np.kind == pass) host.push_back(jobs[i]->mj);
+        if (pass == 1) n_lab = (int) host.size();
+    }
+    if (host.empty()) return NQ_OK;
+    NQ_HIP(owner, owner->d_jobs.reserve(host.size()));
+    NQ_HIP(owner, hipMemcpyAsync(owner->d_jobs.p, host.data(), host.size() * sizeof(nq::MergeJob), hipMemcpyHostToDevice, owner->stream));
+    NQ_HIP(owner, hipStreamSynchronize(owner->stream));    // `host` goes out of scope
+    launch_merge(1, owner->d_jobs.p, n_lab, owner->stream);
+    launch_merge(0, owner->d_jobs.p + n_lab, (int) host.size() - n_lab, owner->stream);
+    NQ_HIP(owner, hipGetLastError());
+    return NQ_OK;
+}
+
+// palette fill (P10) + read-back
+int palette_finish(nq_handle* h, const PaletteJob& job, uint32_t* out_palette, int32_t* out_K) {
+    nq_params& p = h->params;
+    const int plen = job.plen;
     NQ_HIP(h, h->d_palette.reserve((size_t) std::max(plen, 2)));
     int* d_status = h->d_ints.p + 1;
-    launch_palette_fill(kind, B, maxbins, plen, h->d_palette.p, d_status, h->stream);
+    launch_palette_fill(h->kind, job.mj.B, job.mj.maxbins, plen, h->d_palette.p, d_status, h->stream);
     rec(h, 5);
     int status = 0;
     NQ_HIP(h, hipMemcpyAsync(out_palette, h->d_palette.p, plen * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -454,7 +499,22 @@ int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMax
     return NQ_OK;
 }
 
-int pnnquan_device(nq_handle* h, const uint32_t* d_argb, int width, int height, int nMaxColors, uint32_t* out_palette, int32_t* out_K) {
+int palette_from_hist(nq_handle* h, const double* d_hists, int n_bands, int nMaxColors, uint32_t* out_palette, int32_t* out_K,
+                      const uint32_t* d_argb = nullptr, int64_t n_pixels = 0) {
+    PaletteJob job;
+    int rc = palette_prepare(h, d_hists, n_bands, nMaxColors, out_palette, out_K, d_argb, n_pixels, &job);
+    if (rc || !job.merge) return rc;
+    const PaletteJob* jp = &job;
+    rc = merge_launch(h, &jp, 1);
+    if (rc) return rc;
+    rec(h, 4);
+    return palette_finish(h, job, out_palette, out_K);
+}
+
+// alpha pre-scan + histogram + palette_prepare
+int pnnquan_prepare(nq_handle* h, const uint32_t* d_argb, int width, int height, int nMaxColors, uint32_t* out_palette, int32_t* out_K,
+                    PaletteJob* job) {
+    job->merge = false;
     if (!d_argb || width <= 0 || height <= 0 || !out_palette || !out_K) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
     if (nMaxColors < 1 || nMaxColors > 32767) NQ_FAIL(h, NQ_ERR_INVALID, "nMaxColors out of range");
     const int64_t n = (int64_t) width * height;
@@ -483,10 +543,21 @@ int pnnquan_device(nq_handle* h, const uint32_t* d_argb, int width, int height, 
     hp.hasSemi = p.hasSemiTransparency; hp.hasTransp = nMaxColors < 64 || p.transparentPixelIndex >= 0;
     hp.transparentColor = p.transparentColor; hp.rewriteTransparent = 0;
     nq::SortWorkspace ws;
-    ws.keys_a = h->keys_a.p; ws.keys_b = h->keys_b.p; ws.vals_a = h->vals_a.p; ws.vals_b = h->vals_b.p;
-    ws.tmp = h->sort_tmp.p; ws.tmp_bytes = h->sort_tmp.n; ws.seg_start = h->seg.p; ws.seg_end = h->seg.p + 65536;
-    launch_histogram(h->kind, (const int*) d_argb, n, hp, ws, h->hist.p, h->stream);
-    return palette_from_hist(h, h->hist.p, 1, nMaxColors, out_palette, out_K, d_argb, n);
+    ws.keys_a = h->sc->keys_a.p; ws.keys_b = h->sc->keys_b.p; ws.vals_a = h->sc->vals_a.p; ws.vals_b = h->sc->vals_b.p;
+    ws.tmp = h->sc->sort_tmp.p; ws.tmp_bytes = h->sc->sort_tmp.n; ws.seg_start = h->sc->seg.p; ws.seg_end = h->sc->seg.p + 65536;
+    launch_histogram(h->kind, (const int*) d_argb, n, hp, ws, h->sc->hist.p, h->stream);
+    return palette_prepare(h, h->sc->hist.p, 1, nMaxColors, out_palette, out_K, d_argb, n, job);
+}
+
+int pnnquan_device(nq_handle* h, const uint32_t* d_argb, int width, int height, int nMaxColors, uint32_t* out_palette, int32_t* out_K) {
+    PaletteJob job;
+    int rc = pnnquan_prepare(h, d_argb, width, height, nMaxColors, out_palette, out_K, &job);
+    if (rc || !job.merge) return rc;
+    const PaletteJob* jp = &job;
+    rc = merge_launch(h, &jp, 1);
+    if (rc) return rc;
+    rec(h, 4);
+    return palette_finish(h, job, out_palette, out_K);
 }
 
 int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, const uint32_t* palette, int K, int dither,
@@ -566,9 +637,9 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     { int rcl = prepare_lists(h, P, &lv); if (rcl) return rcl; }
     const float* d_sal = nullptr;
     if (hasSal) {
-        NQ_HIP(h, h->saliency.reserve((size_t) n));
-        launch_saliency(P, salSubst ? 1 : 0, (const int*) d_argb, n, h->saliency.p, h->stream);
-        d_sal = h->saliency.p;
+        NQ_HIP(h, h->sc->saliency.reserve((size_t) n));
+        launch_saliency(P, salSubst ? 1 : 0, (const int*) d_argb, n, h->sc->saliency.p, h->stream);
+        d_sal = h->sc->saliency.p;
     }
     rec(h, 5);       // stage "palette_fill" ends here: it includes the candidate-list build and the saliency map
     launch_gilbert(P, G, T, lv, (const int*) d_argb, d_sal, h->d_palette.p, h->d_bincache.p, (long long) seed, sequential ? 1 : 0,
@@ -644,10 +715,10 @@ int nq_set_tile(nq_handle* h, int tile_w, int tile_h) {
 }
 int nq_get_list_counts(nq_handle* h, uint8_t* closest_counts, uint8_t* nearest_counts) {
     if (!h || !closest_counts || !nearest_counts) return NQ_ERR_INVALID;
-    if (!h->cell_lists.p) NQ_FAIL(h, NQ_ERR_INVALID, "no lists built yet");
+    if (!h->sc->cell_lists.p) NQ_FAIL(h, NQ_ERR_INVALID, "no lists built yet");
     const size_t LB = (size_t) 65536 * 32;
-    NQ_HIP(h, hipMemcpy(closest_counts, h->cell_lists.p + 2 * LB, 65536, hipMemcpyDeviceToHost));
-    NQ_HIP(h, hipMemcpy(nearest_counts, h->cell_lists.p + 2 * LB + 65536, 65536, hipMemcpyDeviceToHost));
+    NQ_HIP(h, hipMemcpy(closest_counts, h->sc->cell_lists.p + 2 * LB, 65536, hipMemcpyDeviceToHost));
+    NQ_HIP(h, hipMemcpy(nearest_counts, h->sc->cell_lists.p + 2 * LB + 65536, 65536, hipMemcpyDeviceToHost));
     return NQ_OK;
 }
 int nq_set_option(nq_handle* h, int option, int value) {
@@ -733,6 +804,59 @@ int nq_convert_device(nq_handle* h, const uint32_t* d_argb, int width, int heigh
     if (rc) return rc;
     NQ_HIP(h, hipStreamSynchronize(h->stream));
     finish_timing(h);
+    return NQ_OK;
+}
+
+int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* d_argb, const int32_t* widths, const int32_t* heights,
+                            int nMaxColors, int dither, const int64_t* rng_seeds, int mode,
+                            uint32_t* const* d_out_argb, uint16_t* const* d_out_index,
+                            uint32_t* out_palettes, int32_t palette_stride, int32_t* out_K) {
+    if (!hs || n <= 0 || !hs[0]) return NQ_ERR_INVALID;
+    nq_handle* h0 = hs[0];
+    if (!d_argb || !widths || !heights || !rng_seeds || !d_out_argb || !out_palettes || !out_K)
+        NQ_FAIL(h0, NQ_ERR_INVALID, "bad argument");
+    if (palette_stride < std::max(nMaxColors, 2)) NQ_FAIL(h0, NQ_ERR_INVALID, "palette_stride < max(nMaxColors, 2)");
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]) NQ_FAIL(h0, NQ_ERR_INVALID, "null handle in batch");
+        if (hs[i]->device != h0->device) NQ_FAIL(h0, NQ_ERR_INVALID, "handles of a batch must share one device");
+        for (int j = 0; j < i; ++j) if (hs[j] == hs[i]) NQ_FAIL(h0, NQ_ERR_INVALID, "a handle appears twice in the batch");
+    }
+    // the whole batch runs on the first handle's stream and shares its per-pixel scratch (stages of different images never overlap)
+    struct Restore {
+        nq_handle* const* hs; int n; std::vector<hipStream_t> streams;
+        ~Restore() { for (int i = 0; i < n; ++i) { hs[i]->stream = streams[i]; hs[i]->sc = &hs[i]->own; } }
+    } restore{hs, n, {}};
+    for (int i = 0; i < n; ++i) restore.streams.push_back(hs[i]->stream);
+    auto fail_from = [&](nq_handle* h, int rc) { if (h != h0) h0->err = h->err; return rc; };
+    for (int i = 0; i < n; ++i) {
+        int rc = use_device(hs[i]);            // tables / events on the handle's own stream, before it is redirected
+        if (rc) return fail_from(hs[i], rc);
+        if (i) NQ_HIP(h0, hipStreamSynchronize(hs[i]->stream));
+        hs[i]->stream = h0->stream; hs[i]->sc = &h0->own;
+    }
+    std::vector<PaletteJob> jobs(n);
+    std::vector<const PaletteJob*> jp(n);
+    for (int i = 0; i < n; ++i) {
+        int rc = pnnquan_prepare(hs[i], d_argb[i], widths[i], heights[i], nMaxColors, out_palettes + (size_t) i * palette_stride,
+                                 out_K + i, &jobs[i]);
+        if (rc) return fail_from(hs[i], rc);
+        jp[i] = &jobs[i];
+    }
+    int rc = merge_launch(h0, jp.data(), n);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) if (jobs[i].merge) rec(hs[i], 4);
+    for (int i = 0; i < n; ++i) {
+        uint32_t* pal = out_palettes + (size_t) i * palette_stride;
+        if (jobs[i].merge) {
+            rc = palette_finish(hs[i], jobs[i], pal, out_K + i);
+            if (rc) return fail_from(hs[i], rc);
+        }
+        rc = dither_device(hs[i], d_argb[i], widths[i], heights[i], pal, out_K[i], dither, rng_seeds[i], mode, d_out_argb[i],
+                           d_out_index ? d_out_index[i] : nullptr);
+        if (rc) return fail_from(hs[i], rc);
+    }
+    NQ_HIP(h0, hipStreamSynchronize(h0->stream));
+    for (int i = 0; i < n; ++i) finish_timing(hs[i]);
     return NQ_OK;
 }
 
@@ -823,8 +947,8 @@ int nq_band_histogram_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pix
     hp.hasSemi = p.hasSemiTransparency; hp.hasTransp = p.nMaxColors < 64 || p.transparentPixelIndex >= 0;
     hp.transparentColor = p.transparentColor; hp.rewriteTransparent = 0;
     nq::SortWorkspace ws;
-    ws.keys_a = h->keys_a.p; ws.keys_b = h->keys_b.p; ws.vals_a = h->vals_a.p; ws.vals_b = h->vals_b.p;
-    ws.tmp = h->sort_tmp.p; ws.tmp_bytes = h->sort_tmp.n; ws.seg_start = h->seg.p; ws.seg_end = h->seg.p + 65536;
+    ws.keys_a = h->sc->keys_a.p; ws.keys_b = h->sc->keys_b.p; ws.vals_a = h->sc->vals_a.p; ws.vals_b = h->sc->vals_b.p;
+    ws.tmp = h->sc->sort_tmp.p; ws.tmp_bytes = h->sc->sort_tmp.n; ws.seg_start = h->sc->seg.p; ws.seg_end = h->sc->seg.p + 65536;
     launch_histogram(h->kind, (const int*) d_argb, n_pixels, hp, ws, d_hist, h->stream);
     NQ_HIP(h, hipGetLastError());
     return NQ_OK;

@@ -102,10 +102,17 @@ void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams
 void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, hipStream_t s);
 void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s);
 void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, hipStream_t s);
-// d_live3: int[3*65536] scratch (two live lists + position index); d_stats: long long[8] (see merge_kernel)
-// d_heap: int[2*(65536+2)] (ids, then float keys); d_scan_f: float[2*6*65536]; d_scan_i: int[2*65536]
-void launch_merge(const NNParams& np, const Bins& B, int maxbins, int extbins, int* d_heap, int* d_live3, float* d_scan_f,
-                  int* d_scan_i, long long* d_stats, hipStream_t s);
+// One merge loop (P9).  heap: int[2*(65536+2)] (ids, then float keys); live3: int[3*65536] (two live lists + position index);
+// scan_f: float[2*6*65536], scan_i: int[2*65536] (LAB scan arrays, two generations); stats: long long[16] (see merge_kernel)
+struct MergeJob {
+    NNParams np;
+    Bins B;
+    int maxbins, extbins;
+    int* heap; int* live3; float* scan_f; int* scan_i;
+    long long* stats;
+};
+// d_jobs: n jobs of one kind in device memory; one workgroup (one CU) per job
+void launch_merge(int kind, const MergeJob* d_jobs, int n, hipStream_t s);
 void launch_palette_fill(int kind, const Bins& B, int maxbins, int plen, int* d_palette, int* d_status, hipStream_t s);
 
 } // namespace nq

@@ -185,20 +185,17 @@ void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, hipStre
     if (np.kind == 1) hipLaunchKernelGGL(find_nn_init_kernel<1>, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
     else hipLaunchKernelGGL(find_nn_init_kernel<0>, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
 }
-void launch_merge(const NNParams& np, const Bins& B, int maxbins, int extbins, int* d_heap, int* d_live3, float* d_scan_f,
-                  int* d_scan_i, long long* d_stats, hipStream_t s) {
-    MergeParams mp; mp.maxbins = maxbins; mp.extbins = extbins;
+void launch_merge(int kind, const MergeJob* d_jobs, int n, hipStream_t s) {
+    if (n <= 0) return;
     const size_t dyn = sizeof(MergeLds);
-    int* liveA = d_live3; int* liveB = d_live3 + 65536; int* livepos = d_live3 + 2 * 65536;
-    int* hid = d_heap; float* herr = reinterpret_cast<float*>(d_heap + 65536 + 2);
-    if (np.kind == 1) {
+    if (kind == 1) {
         static bool attr1 = false;
         if (!attr1) { (void) hipFuncSetAttribute((const void*) merge_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn); attr1 = true; }
-        hipLaunchKernelGGL(merge_kernel<1>, dim3(1), dim3(NQ_MERGE_THREADS), dyn, s, np, B, mp, hid, herr, liveA, liveB, livepos, d_scan_f, d_scan_i, d_stats);
+        hipLaunchKernelGGL(merge_kernel<1>, dim3(n), dim3(NQ_MERGE_THREADS), dyn, s, d_jobs);
     } else {
         static bool attr0 = false;
         if (!attr0) { (void) hipFuncSetAttribute((const void*) merge_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn); attr0 = true; }
-        hipLaunchKernelGGL(merge_kernel<0>, dim3(1), dim3(NQ_MERGE_THREADS), dyn, s, np, B, mp, hid, herr, liveA, liveB, livepos, d_scan_f, d_scan_i, d_stats);
+        hipLaunchKernelGGL(merge_kernel<0>, dim3(n), dim3(NQ_MERGE_THREADS), dyn, s, d_jobs);
     }
 }
 void launch_palette_fill(int kind, const Bins& B, int maxbins, int plen, int* d_palette, int* d_status, hipStream_t s) {

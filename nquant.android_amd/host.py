@@ -20,7 +20,7 @@ _LIB = None
 
 ABI_SYMBOLS = [
     "nq_abi_version", "nq_create", "nq_destroy", "nq_last_error", "nq_set_stream", "nq_set_tile", "nq_set_option", "nq_get_list_counts", "nq_get_params",
-    "nq_set_params", "nq_convert", "nq_convert_device", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
+    "nq_set_params", "nq_convert", "nq_convert_device", "nq_convert_batch_device", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
     "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_get_stage_ms", "nq_get_merge_stats",
 ]
@@ -99,6 +99,7 @@ def load_library():
     L.nq_set_params.argtypes = [vp, C.POINTER(Params)]
     L.nq_convert.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, C.POINTER(C.c_int32)]
     L.nq_convert_device.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, C.POINTER(C.c_int32)]
+    L.nq_convert_batch_device.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp]
     L.nq_pnnquan.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(C.c_int32)]
     L.nq_pnnquan_device.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(C.c_int32)]
     L.nq_dither.argtypes = [vp, vp, i32, i32, vp, i32, i32, i64, i32, vp, vp]
@@ -279,6 +280,30 @@ class PnnQuantizer:
                                              int(bool(dither)), int(self.seed if seed is None else seed),
                                              int(self.mode if mode is None else mode), C.c_void_p(d_out_argb),
                                              C.c_void_p(d_out_index or None)))
+
+
+def convert_batch_device(quantizers, d_pixels, nMaxColors, dither, d_out_argb, d_out_index=None, mode=None, seeds=None):
+    """nq_convert_batch_device: convert() of several quantizer objects in one call -- their merge loops run side by side in one
+    launch.  `quantizers[i].width/height` describe image i, `d_pixels[i]`, `d_out_argb[i]`, `d_out_index[i]` are HIP device
+    addresses.  Returns the list of palettes; results equal len(quantizers) separate convert_device calls."""
+    n = len(quantizers)
+    if n == 0:
+        return []
+    q0 = quantizers[0]
+    hs = (C.c_void_p * n)(*[q._h for q in quantizers])
+    src = (C.c_void_p * n)(*[int(a) for a in d_pixels])
+    dst = (C.c_void_p * n)(*[int(a) for a in d_out_argb])
+    idx = (C.c_void_p * n)(*[int(a) for a in d_out_index]) if d_out_index is not None else None
+    widths = np.array([q.width for q in quantizers], np.int32)
+    heights = np.array([q.height for q in quantizers], np.int32)
+    sd = np.array([q.seed for q in quantizers] if seeds is None else list(seeds), np.int64)
+    stride = max(int(nMaxColors), 2)
+    pal = np.zeros((n, stride), np.int32)
+    K = np.zeros(n, np.int32)
+    q0._check(q0._L.nq_convert_batch_device(hs, n, src, widths.ctypes.data, heights.ctypes.data, int(nMaxColors), int(bool(dither)),
+                                            sd.ctypes.data, int(q0.mode if mode is None else mode), dst, idx, pal.ctypes.data,
+                                            stride, K.ctypes.data))
+    return [pal[i, :K[i]].copy() for i in range(n)]
 
 
 class PnnLABQuantizer(PnnQuantizer):

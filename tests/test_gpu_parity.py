@@ -331,3 +331,44 @@ def test_two_band_rgb_palette_equals_whole_image(nq, oracle):
     op, gp = oq.params, q.params
     assert (op.transparentPixelIndex, op.transparentColor, op.hasSemiTransparency, op.maxbins) == \
            (gp.transparentPixelIndex, gp.transparentColor, gp.hasSemiTransparency, gp.maxbins)
+
+
+def test_convert_batch_equals_single_converts(nq):
+    """nq_convert_batch_device (all merge loops in one launch, shared scratch, one stream) == one nq_convert_device per image:
+    mixed kinds, sizes, an image with alpha, a few-colours image (early return, no merge job)."""
+    import torch
+    imgs = [(1, synth.gradient_noise(144, 112, 81)), (0, synth.uniform_rgb(96, 80, 82)),
+            (1, synth.with_alpha(synth.gradient_noise(80, 120, 83), 83)), (1, synth.few_colors(64, 64, 84, 100)),
+            (0, synth.gradient_noise(128, 64, 85)), (1, synth.uniform_rgb(72, 72, 86))]
+    cls = {0: nq.PnnQuantizer, 1: nq.PnnLABQuantizer}
+    d_in = [torch.from_numpy(np.ascontiguousarray(im).reshape(-1)).cuda() for _, im in imgs]
+
+    def fresh():
+        qs = []
+        for i, (kind, im) in enumerate(imgs):
+            q = cls[kind](np.zeros((1, 1), np.int32), mode=TILED, seed=7 + i, tile=(16, 16))
+            q.height, q.width = im.shape
+            qs.append(q)
+        return qs
+
+    single = []
+    for q, d in zip(fresh(), d_in):
+        out = torch.empty_like(d)
+        idx = torch.empty(d.numel(), dtype=torch.int16, device="cuda")
+        pal = q.convert_device(d.data_ptr(), 256, True, out.data_ptr(), idx.data_ptr())
+        single.append((pal, out.cpu().numpy(), idx.cpu().numpy()))
+    qs = fresh()
+    outs = [torch.empty_like(d) for d in d_in]
+    idxs = [torch.empty(d.numel(), dtype=torch.int16, device="cuda") for d in d_in]
+    pals = nq.convert_batch_device(qs, [d.data_ptr() for d in d_in], 256, True, [o.data_ptr() for o in outs],
+                                   [x.data_ptr() for x in idxs])
+    torch.cuda.synchronize()
+    for i in range(len(imgs)):
+        assert len(pals[i]) == len(single[i][0]) and (pals[i] != single[i][0]).sum() == 0, i
+        assert (outs[i].cpu().numpy() != single[i][1]).sum() == 0, i
+        assert (idxs[i].cpu().numpy() != single[i][2]).sum() == 0, i
+        assert qs[i].stage_ms()["total"] > 0
+    # the handles are usable one by one again afterwards (stream / scratch restored)
+    again = torch.empty_like(d_in[0])
+    pal0 = qs[0].convert_device(d_in[0].data_ptr(), 256, True, again.data_ptr())
+    assert (pal0 != single[0][0]).sum() == 0 and (again.cpu().numpy() != single[0][1]).sum() == 0
