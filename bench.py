@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of BASELINE.json: Mpixels/s, 4096x4096 RGBA -> 256-colour PnnLAB + dither.
 
-One "step" = one whole convert(256, dither=true) of a 4096x4096 ARGB image that is already resident in HBM:
-alpha pre-scan, histogram, find_nn, merge loop, palette fill, gilbert-curve error diffusion (PARALLEL_TILED).
-Multi-GPU (driver: torch.distributed.run, one rank per GPU): every rank converts its own image (independent units,
+One "step" = one batch (--batch, default 256) of distinct 4096x4096 ARGB images, already resident in HBM, each through the
+whole convert(256, dither=true): alpha pre-scan, histogram, find_nn, merge loop, palette fill, gilbert-curve error diffusion
+(PARALLEL_TILED).  The merge loop of one image is a sequential chain on one CU, so images are handed over in batches
+(nq_convert_batch_device): the merge loops of a batch run side by side, one workgroup each.
+Multi-GPU (driver: torch.distributed.run, one rank per GPU): every rank converts its own batches (independent units,
 no data-path collective; RCCL only for the barrier / max-over-ranks of the time) -> "scaling": "weak".
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) with two extra objects:
@@ -71,15 +73,18 @@ def measured_traffic(w, h):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--steps", type=int, default=4, help="one step = one batch of --batch images through the whole hot path")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform"])
     ap.add_argument("--tile", type=int, default=0, help="tile side of the PARALLEL_TILED decomposition (0 = automatic)")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="side of the CPU-baseline sample image (0 = skip)")
-    ap.add_argument("--concurrency", type=int, default=24,
-                    help="independent converts in flight per GPU, each on its own HIP stream and quantizer handle (the merge "
-                         "loop of one convert is a sequential chain on one CU; other converts fill the rest of the chip)")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="images per step (distinct synthetic images, all resident in HBM): the merge loop of one image is a "
+                         "sequential chain on one CU, a batch runs its merge loops side by side (nq_convert_batch_device)")
+    ap.add_argument("--concurrency", type=int, default=2,
+                    help="host threads / HIP streams a step's batch is split over, so that the per-pixel stages of one sub-batch "
+                         "overlap the merge loops of another")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,59 +101,78 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
+    import threading
     import nquant.android_amd as nq
     from nquant.android_amd import synth
     nq.build_library()
 
     W = H = args.size
     npx = W * H
-    seed = 3 + rank
-    img = synth.gradient_noise(W, H, seed) if args.workload == "gradient_noise" else synth.uniform_rgb(W, H, seed)
-    d_in = torch.from_numpy(img.reshape(-1)).cuda()
-    d_out = torch.empty(npx, dtype=torch.int32, device="cuda")
-    d_idx = torch.empty(npx, dtype=torch.int16, device="cuda")
+    Bn = max(1, args.batch)
+    T = max(1, min(args.concurrency, Bn))
     tile = args.tile
     if tile <= 0:      # the library's automatic rule (nq_set_tile): largest of 16, 8, 4 with >= 131072 tiles
         tile = next((c for c in (16, 8) if ((W + c - 1) // c) * ((H + c - 1) // c) >= 131072), 4)
-    import threading
-    C = max(1, min(args.concurrency, max(args.steps, 1)))
-    lanes = []
-    for c in range(C):
+
+    # the batch: Bn distinct images (seed 3 + rank * Bn + slot), inputs and outputs resident in HBM
+    slots = []
+    uniform = None
+    if args.workload == "uniform":
+        uniform = [torch.from_numpy(synth.uniform_rgb(W, H, 3 + rank * 8 + k).reshape(-1)).cuda() for k in range(min(8, Bn))]
+    for b in range(Bn):
+        seed = 3 + rank * Bn + b
+        d_in = synth.gradient_noise_torch(W, H, seed) if uniform is None else uniform[b % len(uniform)]
+        q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), device=local_rank, mode=nq.MODE_PARALLEL_TILED, seed=seed,
+                               tile=(tile, tile))
+        q.width, q.height = W, H
+        slots.append({"q": q, "in": d_in, "out": torch.empty(npx, dtype=torch.int32, device="cuda"),
+                      "idx": torch.empty(npx, dtype=torch.int16, device="cuda")})
+    torch.cuda.synchronize()
+    share = [Bn // T + (1 if t < Bn % T else 0) for t in range(T)]
+    groups, o = [], 0
+    for t in range(T):
+        g = slots[o:o + share[t]]
+        o += share[t]
         st = torch.cuda.Stream()
-        qq = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), device=local_rank, mode=nq.MODE_PARALLEL_TILED, seed=seed,
-                                tile=(tile, tile))
-        qq.width, qq.height = W, H
-        qq.set_stream(st.cuda_stream)
-        lanes.append({"q": qq, "stream": st,
-                      "out": torch.empty(npx, dtype=torch.int32, device="cuda"),
-                      "idx": torch.empty(npx, dtype=torch.int16, device="cuda"),
-                      "stages": {}, "n": 0, "pal": None})
-    q = lanes[0]["q"]
+        g[0]["q"].set_stream(st.cuda_stream)          # a batch runs on its first handle's stream
+        groups.append({"slots": g, "stream": st, "stages": {}, "n": 0, "pals": None, "err": None})
 
-    def run_lane(ln, nsteps, record):
-        # one host thread per lane: the C ABI blocks only on its own stream (ctypes releases the GIL)
-        for _ in range(nsteps):
-            ln["pal"] = ln["q"].convert_device(d_in.data_ptr(), 256, True, ln["out"].data_ptr(), ln["idx"].data_ptr())
-            if record:
-                for k, v in ln["q"].stage_ms().items():      # HIP events recorded on the launch stream, per stage
-                    ln["stages"][k] = ln["stages"].get(k, 0.0) + v
-                ln["n"] += 1
+    def run_group(gr, nsteps, record):
+        # one host thread per sub-batch: the C ABI blocks only on its own stream (ctypes releases the GIL)
+        try:
+            sl = gr["slots"]
+            for _ in range(nsteps):
+                gr["pals"] = nq.convert_batch_device([s["q"] for s in sl], [s["in"].data_ptr() for s in sl], 256, True,
+                                                     [s["out"].data_ptr() for s in sl], [s["idx"].data_ptr() for s in sl])
+                if record:
+                    for s in sl:
+                        for k, v in s["q"].stage_ms().items():      # HIP events recorded on the launch stream, per stage
+                            gr["stages"][k] = gr["stages"].get(k, 0.0) + v
+                        gr["n"] += 1
+        except Exception as e:          # surfaced after the join
+            gr["err"] = e
 
-    def run_all(total, record):
-        share = [total // C + (1 if c < total % C else 0) for c in range(C)]
-        th = [threading.Thread(target=run_lane, args=(lanes[c], share[c], record)) for c in range(C) if share[c] > 0]
+    def run_all(nsteps, record):
+        th = [threading.Thread(target=run_group, args=(gr, nsteps, record)) for gr in groups]
         for t in th:
             t.start()
         for t in th:
             t.join()
+        for gr in groups:
+            if gr["err"] is not None:
+                raise gr["err"]
 
+    # single-convert latency (one image, one stream, nothing else in flight), untimed
+    q0 = slots[0]["q"]
+    q0.convert_device(slots[0]["in"].data_ptr(), 256, True, slots[0]["out"].data_ptr(), slots[0]["idx"].data_ptr())
     torch.cuda.synchronize()
-    # single-convert latency (one stream, nothing else in flight), untimed part of the warm-up
     t0 = time.perf_counter()
-    run_lane(lanes[0], 1, False)
+    q0.convert_device(slots[0]["in"].data_ptr(), 256, True, slots[0]["out"].data_ptr(), slots[0]["idx"].data_ptr())
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t0) * 1e3
-    run_all(max(args.warmup, C), False)
+    single_stages = q0.stage_ms()
+    single_merge_stats = q0.merge_stats()
+    run_all(args.warmup, False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -166,31 +190,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stages = {}
-    nrec = sum(ln["n"] for ln in lanes)
-    for ln in lanes:
-        for k, v in ln["stages"].items():
+    nrec = sum(gr["n"] for gr in groups)
+    for gr in groups:
+        for k, v in gr["stages"].items():
             stages[k] = stages.get(k, 0.0) + v
     stages = {k: v / max(nrec, 1) for k, v in stages.items()}
-    pal = lanes[0]["pal"]
+    pals = groups[0]["pals"]
+    # sanity of the timed work itself: every output pixel is its palette entry
+    s0 = slots[0]
+    palt = torch.from_numpy(pals[0]).cuda()
+    ok = bool((palt[(s0["idx"].to(torch.int64) & 0xFFFF)] == s0["out"]).all())
+    if not ok:
+        raise SystemExit("bench: output pixels do not match palette[index]")
 
     if rank == 0:
-        p = q.params
+        p = q0.params
         kernel_ms = stages["dither"]
         achieved = BYTES_PER_PIXEL * npx / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        images = args.steps * Bn
         line = {
             "metric": "Mpixels/sec, 4096x4096 RGBA -> 256-colour PnnLAB + dither",
-            "value": round(world * args.steps * npx / dt / 1e6, 3),
+            "value": round(world * images * npx / dt / 1e6, 3),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%d ARGB_8888 %s (seed 3+rank), PnnLABQuantizer.convert(256, dither=true), "
-                                   "PARALLEL_TILED %dx%d tiles, one image per rank per step" % (W, H, args.workload, tile, tile),
-                       "palette": int(len(pal)), "maxbins": int(p.maxbins), "parallelism": "1 image per GPU per step, no collective",
-                       "concurrency": C, "single_convert_latency_ms": round(latency_ms, 2)},
+            "config": {"workload": "%dx%d ARGB_8888 %s, PnnLABQuantizer.convert(256, dither=true), PARALLEL_TILED %dx%d tiles; "
+                                   "one step = a batch of %d distinct images per rank (seeds 3 + rank*batch + slot), resident in HBM"
+                                   % (W, H, args.workload, tile, tile, Bn),
+                       "palette": int(len(pals[0])), "maxbins": int(p.maxbins),
+                       "parallelism": "independent images per GPU, no collective",
+                       "batch": Bn, "concurrency": T, "images_per_s": round(world * images / dt, 2),
+                       "ms_per_image": round(dt / images * 1e3, 3),
+                       "single_convert_latency_ms": round(latency_ms, 2)},
             "stages_ms": {k: round(v, 3) for k, v in stages.items()},
-            "merge_stats": q.merge_stats(),
+            "single_convert_stages_ms": {k: round(v, 3) for k, v in single_stages.items()},
+            "merge_stats": single_merge_stats,
             "pass_mpixels_s": round(npx / (kernel_ms * 1e-3) / 1e6, 1) if kernel_ms > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "gilbert_kernel<false,25> (per-pixel nearest/closest colour + error diffusion)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

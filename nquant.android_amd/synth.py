@@ -68,3 +68,35 @@ def few_colors(width, height, seed, ncolors):
     z = splitmix64(seed, width * height)
     pal = (splitmix64(seed ^ 0x5EED, ncolors) & np.uint64(0xFFFFFF)).astype(np.uint32) | np.uint32(0xFF000000)
     return pal[(z % np.uint64(ncolors)).astype(np.int64)].view(np.int32).reshape(height, width)
+
+
+def gradient_noise_torch(width, height, seed, device="cuda", noise=24):
+    """gradient_noise() generated on the device with torch (bench.py fills a whole batch of distinct images this way): the same
+    integer stream and float64 formulae; a device sin() that differs from numpy's in the last place can move a blue value that
+    sits exactly on a rounding boundary, nothing else.  Returns a flat int32 tensor of width*height ARGB pixels."""
+    import torch
+
+    def s64(v):
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(t, k):
+        return (t >> k) & ((1 << (64 - k)) - 1)
+
+    n = width * height
+    i = torch.arange(n, dtype=torch.int64, device=device)
+    z = i + int(seed) + s64(0x9E3779B97F4A7C15)
+    z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    y = torch.div(i, width, rounding_mode="floor")
+    x = i - y * width
+    fx = x.double() / max(width - 1, 1)
+    fy = y.double() / max(height - 1, 1)
+    nr = (z & 0xFF).double() / 255.0 - 0.5
+    ng = ((z >> 8) & 0xFF).double() / 255.0 - 0.5
+    nb = ((z >> 16) & 0xFF).double() / 255.0 - 0.5
+    r = torch.clamp(torch.round(255.0 * fx + noise * nr), 0, 255).long()
+    g = torch.clamp(torch.round(255.0 * fy + noise * ng), 0, 255).long()
+    b = torch.clamp(torch.round(127.5 * (1.0 + torch.sin(2.0 * np.pi * (0.75 * fx + 0.5 * fy))) + noise * nb), 0, 255).long()
+    v = (255 << 24) | (r << 16) | (g << 8) | b
+    return (v - ((v >> 31) << 32)).to(torch.int32)          # reinterpret the low 32 bits as a signed int32
