@@ -173,7 +173,7 @@ int nq_get_stage_ms(const nq_handle* h, float* out8);
 /* Counters of the last merge loop (diagnostics), 16 values: {find_nn calls, merges, 100 MHz ticks inside find_nn, ticks in
  * the sequential heap/merge section, live-list rebuilds, find_nn list overflows, candidates evaluated exactly, ticks in
  * the bound pass, ticks in the exact pass, ticks in the replay, 64-candidate chunks visited, chunks that ran the level-1
- * bound, chunks that ran the tight bound, chunks that listed a candidate, 0, 0}. */
+ * bound, chunks that ran the tight bound, chunks that listed a candidate, aborted flag, ticks of the seed round inside the bound pass}. */
 int nq_get_merge_stats(const nq_handle* h, int64_t* out16);
 
 #ifdef __cplusplus

@@ -103,7 +103,7 @@ void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B,
 void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s);
 void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, hipStream_t s);
 // One merge loop (P9).  heap: int[2*(65536+2)] (ids, then float keys); live3: int[3*65536] (two live lists + position index);
-// scan_f: float[2*6*65536], scan_i: int[2*65536] (LAB scan arrays, two generations); stats: long long[16] (see merge_kernel)
+// scan_f: float[2*6*65536 + 256] (a scan may read 63 records past the live list), scan_i: int[2*65536] (LAB scan arrays, two generations); stats: long long[16] (see merge_kernel)
 struct MergeJob {
     NNParams np;
     Bins B;

@@ -206,7 +206,7 @@ class PnnQuantizer:
         a = (C.c_int64 * 16)()
         self._check(self._L.nq_get_merge_stats(self._h, a))
         return dict(zip(["find_nn_calls", "merges", "find_ticks_100MHz", "ctrl_ticks_100MHz", "rebuilds", "overflows", "exact_evals",
-                         "bound_ticks", "exact_ticks", "replay_ticks", "chunks", "chunks_l1", "chunks_l2", "chunks_listed"], list(a)[:14]))
+                         "bound_ticks", "exact_ticks", "replay_ticks", "chunks", "chunks_l1", "chunks_l2", "chunks_listed", "aborted", "seed_round_ticks"], list(a)[:16]))
 
     # -- the reference interface --
     def hasAlpha(self):

@@ -1,0 +1,23 @@
+"""Single-convert latency and merge-loop counters on the bench image (4096^2 gradient+noise, LAB, 256 colours)."""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np, torch
+import nquant.android_amd as nq
+from nquant.android_amd import synth
+W = H = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+kind = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+d_in = synth.gradient_noise_torch(W, H, 3)
+out = torch.empty_like(d_in); idx = torch.empty(W * H, dtype=torch.int16, device="cuda")
+q = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(np.zeros((1, 1), np.int32), mode=1, seed=3)
+q.width, q.height = W, H
+for it in range(2):
+    t0 = time.perf_counter()
+    pal = q.convert_device(d_in.data_ptr(), 256, True, out.data_ptr(), idx.data_ptr())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+st = q.merge_stats(); n = max(st["find_nn_calls"], 1)
+print("latency %.1f ms  stages %s" % (dt * 1e3, {k: round(v, 2) for k, v in q.stage_ms().items()}))
+print("finds %d merges %d | per find us: total %.2f ctrl %.2f bound %.2f (seed %.2f) exact %.2f replay %.2f | chunks %.1f l1 %.1f l2 %.1f listed %.1f exact %.2f" % (
+    n, st["merges"], st["find_ticks_100MHz"] / n / 100, st["ctrl_ticks_100MHz"] / n / 100, st["bound_ticks"] / n / 100,
+    st["seed_round_ticks"] / n / 100, st["exact_ticks"] / n / 100, st["replay_ticks"] / n / 100, st["chunks"] / n, st["chunks_l1"] / n,
+    st["chunks_l2"] / n, st["chunks_listed"] / n, st["exact_evals"] / n))
