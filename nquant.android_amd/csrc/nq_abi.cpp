@@ -162,6 +162,7 @@ struct nq_handle {
     int use_lists = 1;
     DevBuf<float> scan_f;             // merge loop: position-indexed scan arrays (two generations)
     DevBuf<int> scan_i;
+    DevBuf<float> scan_box;           // merge loop: bounding boxes of the 64-position blocks (1024 x 8 floats)
     DevBuf<nq::MergeJob> d_jobs;      // merge jobs of the current call (1, or the whole batch on the first handle)
     long long merge_stats[16] = {0};
     DevBuf<int> d_ints;               // [0] maxbins, [1] status
@@ -281,6 +282,7 @@ int reserve_palette_ws(nq_handle* h, int64_t n) {
     NQ_HIP(h, h->bini.reserve((size_t) 3 * 65536)); NQ_HIP(h, h->heap.reserve(2 * (65536 + 2)));
     NQ_HIP(h, h->live3.reserve((size_t) 3 * 65536));
     NQ_HIP(h, h->scan_f.reserve((size_t) 2 * 6 * 65536 + 256)); NQ_HIP(h, h->scan_i.reserve((size_t) 2 * 65536));
+    NQ_HIP(h, h->scan_box.reserve((size_t) 1024 * 8));
     return NQ_OK;
 }
 
@@ -453,7 +455,7 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
     const int extbins = maxbins - nMaxColors;
     job->merge = true;
     job->mj.np = np; job->mj.B = B; job->mj.maxbins = maxbins; job->mj.extbins = extbins;
-    job->mj.heap = h->heap.p; job->mj.live3 = h->live3.p; job->mj.scan_f = h->scan_f.p; job->mj.scan_i = h->scan_i.p;
+    job->mj.heap = h->heap.p; job->mj.live3 = h->live3.p; job->mj.scan_f = h->scan_f.p; job->mj.scan_i = h->scan_i.p; job->mj.scan_box = h->scan_box.p;
     job->mj.stats = h->d_scalars.p + 4;
     job->plen = extbins > 0 ? nMaxColors : maxbins;
     return NQ_OK;

@@ -109,6 +109,7 @@ struct MergeJob {
     Bins B;
     int maxbins, extbins;
     int* heap; int* live3; float* scan_f; int* scan_i;
+    float* scan_box;            // float[1024 * 8]: bounding boxes of the 64-position blocks of the LAB scan arrays
     long long* stats;
 };
 // d_jobs: n jobs of one kind in device memory; one workgroup (one CU) per job
