@@ -182,7 +182,7 @@ void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s) {
 }
 void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, hipStream_t s) {
     if (maxbins <= 0) return;
-    if (np.kind == 1) hipLaunchKernelGGL(find_nn_init_kernel<1>, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
+    if (np.kind == 1) hipLaunchKernelGGL(find_nn_init_lab_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
     else hipLaunchKernelGGL(find_nn_init_kernel<0>, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
 }
 void launch_merge(int kind, const MergeJob* d_jobs, int n, hipStream_t s) {
