@@ -518,21 +518,18 @@ __device__ __forceinline__ void closest_step_lab(const DevParams& P, const PalVi
                                                  double wr, double wg, double wb, double ratio, int closest[4]) {
     const int c2 = pal.argb[k];
     const int dr = c_red(c2) - cr, dg = c_green(c2) - cg, db = c_blue(c2) - cb;
+    // Every term is >= 0 and every gate of the reference (`if (err >= closest[3]) break`) only leaves early a candidate whose
+    // final err would be >= closest[3] as well, i.e. one that neither branch below takes: the sum is evaluated straight through,
+    // same operations in the same order, and compared once (no divergent exits between twelve short terms).
     double err = wr * sqr((double) dr);
-    if (err >= closest[3]) return;
     err += wg * sqr((double) dg);
-    if (err >= closest[3]) return;
     err += wb * sqr((double) db);
-    if (err >= closest[3]) return;
     if (P.hasSemi) err += P.PA * sqr((double) (c_alpha(c2) - ca));
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         err += ratio * sqr((double) (k_coeffs[i][0] * dr));
-        if (err >= closest[3]) break;
         err += ratio * sqr((double) (k_coeffs[i][1] * dg));
-        if (err >= closest[3]) break;
         err += ratio * sqr((double) (k_coeffs[i][2] * db));
-        if (err >= closest[3]) break;
     }
     if (err < closest[2]) {
         closest[1] = closest[0]; closest[3] = closest[2];
