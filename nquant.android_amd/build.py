@@ -11,7 +11,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 DEVICE_SOURCES = ["nq_kernels.hip"]
 HOST_SOURCES = ["nq_abi.cpp"]
-DEPS = ["nq_device.h", "nq_kernels.h", "nq_dither.inc", "nq_palette.inc",
+DEPS = ["nq_device.h", "nq_kernels.h", "nq_dither.inc", "nq_palette.inc", "nq_merge.inc", "nq_lists.inc",
         os.path.join("..", "..", "include", "nquant_abi.h"), os.path.join("..", "..", "include", "nq_blue_noise_64x64.inc")]
 
 

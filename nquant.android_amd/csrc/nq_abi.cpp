@@ -474,8 +474,8 @@ int merge_launch(nq_handle* owner, const PaletteJob* const* jobs, int n) {
     NQ_HIP(owner, owner->d_jobs.reserve(host.size()));
     NQ_HIP(owner, hipMemcpyAsync(owner->d_jobs.p, host.data(), host.size() * sizeof(nq::MergeJob), hipMemcpyHostToDevice, owner->stream));
     NQ_HIP(owner, hipStreamSynchronize(owner->stream));    // `host` goes out of scope
-    launch_merge(1, owner->d_jobs.p, n_lab, owner->stream);
-    launch_merge(0, owner->d_jobs.p + n_lab, (int) host.size() - n_lab, owner->stream);
+    launch_merge(1, owner->d_jobs.p, n_lab, (int) host.size(), owner->stream);
+    launch_merge(0, owner->d_jobs.p + n_lab, (int) host.size() - n_lab, (int) host.size(), owner->stream);
     NQ_HIP(owner, hipGetLastError());
     return NQ_OK;
 }

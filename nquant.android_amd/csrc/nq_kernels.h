@@ -112,8 +112,10 @@ struct MergeJob {
     float* scan_box;            // float[1024 * 8]: bounding boxes of the 64-position blocks of the LAB scan arrays
     long long* stats;
 };
-// d_jobs: n jobs of one kind in device memory; one workgroup (one CU) per job
-void launch_merge(int kind, const MergeJob* d_jobs, int n, hipStream_t s);
+// d_jobs: n jobs of one kind in device memory, one workgroup per job.  n_in_flight = merge loops expected to run at the same
+// time on the device (the whole batch): <= 256 -> 512-thread workgroups, one per CU; <= 512 -> 256 threads, two per CU;
+// more -> 128 threads, four per CU
+void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, hipStream_t s);
 void launch_palette_fill(int kind, const Bins& B, int maxbins, int plen, int* d_palette, int* d_status, hipStream_t s);
 
 } // namespace nq

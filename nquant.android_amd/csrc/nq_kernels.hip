@@ -4,6 +4,7 @@
 #include "nq_device.h"
 #include "nq_kernels.h"
 #include <cstring>
+#include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace nq {
@@ -185,17 +186,27 @@ void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, hipStre
     if (np.kind == 1) hipLaunchKernelGGL(find_nn_init_lab_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
     else hipLaunchKernelGGL(find_nn_init_kernel<0>, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
 }
-void launch_merge(int kind, const MergeJob* d_jobs, int n, hipStream_t s) {
+// one workgroup per job; the workgroup size follows the number of jobs in flight (nq_merge.inc)
+template <typename K>
+static void launch_merge_variant(K kernel, size_t dyn, int threads, const MergeJob* d_jobs, int n, hipStream_t s) {
+    (void) hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
+    hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), dyn, s, d_jobs);
+}
+void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, hipStream_t s) {
     if (n <= 0) return;
-    const size_t dyn = sizeof(MergeLds);
-    if (kind == 1) {
-        static bool attr1 = false;
-        if (!attr1) { (void) hipFuncSetAttribute((const void*) merge_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn); attr1 = true; }
-        hipLaunchKernelGGL(merge_kernel<1>, dim3(n), dim3(NQ_MERGE_THREADS), dyn, s, d_jobs);
+    if (const char* f = std::getenv("NQ_MERGE_THREADS")) {       // tests: force one variant (512, 256 or 128)
+        const int t = std::atoi(f);
+        n_in_flight = t == 128 ? 1024 : t == 256 ? 512 : t == 512 ? 1 : n_in_flight;
+    }
+    if (n_in_flight <= 256) {
+        if (kind == 1) launch_merge_variant(m512::merge_kernel<1>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
+        else launch_merge_variant(m512::merge_kernel<0>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
+    } else if (n_in_flight <= 512) {
+        if (kind == 1) launch_merge_variant(m256::merge_kernel<1>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
+        else launch_merge_variant(m256::merge_kernel<0>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
     } else {
-        static bool attr0 = false;
-        if (!attr0) { (void) hipFuncSetAttribute((const void*) merge_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn); attr0 = true; }
-        hipLaunchKernelGGL(merge_kernel<0>, dim3(n), dim3(NQ_MERGE_THREADS), dyn, s, d_jobs);
+        if (kind == 1) launch_merge_variant(m128::merge_kernel<1>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
+        else launch_merge_variant(m128::merge_kernel<0>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
     }
 }
 void launch_palette_fill(int kind, const Bins& B, int maxbins, int plen, int* d_palette, int* d_status, hipStream_t s) {

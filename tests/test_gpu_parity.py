@@ -372,3 +372,23 @@ def test_convert_batch_equals_single_converts(nq):
     again = torch.empty_like(d_in[0])
     pal0 = qs[0].convert_device(d_in[0].data_ptr(), 256, True, again.data_ptr())
     assert (pal0 != single[0][0]).sum() == 0 and (again.cpu().numpy() != single[0][1]).sum() == 0
+
+
+_VARIANT_WANT = {}
+
+
+@pytest.mark.parametrize("threads", [512, 256, 128])
+def test_merge_loop_variants_agree_with_oracle(nq, oracle, threads, monkeypatch):
+    """The merge loop is compiled for three workgroup sizes (csrc/nq_merge.inc; the batch size picks one): every variant must
+    build the oracle's palette bit for bit -- LAB with > 16384 bins (more than the smallest LDS heap / mtm mirrors), LAB with
+    alpha, RGB."""
+    monkeypatch.setenv("NQ_MERGE_THREADS", str(threads))
+    cases = [(1, synth.uniform_rgb(160, 160, 91), 256), (1, synth.with_alpha(synth.gradient_noise(96, 96, 92), 92), 64),
+             (0, synth.gradient_noise(128, 128, 93), 256)]
+    for ci, (kind, img, K) in enumerate(cases):
+        if ci not in _VARIANT_WANT:                      # the oracle's answer does not depend on the variant
+            _VARIANT_WANT[ci] = _oracle_palette(oracle, kind, img, K)[1]
+        want = _VARIANT_WANT[ci]
+        gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=TILED, seed=1)
+        got = gq.pnnquan(K)
+        assert len(got) == len(want) and (got != want).sum() == 0, (threads, kind)
