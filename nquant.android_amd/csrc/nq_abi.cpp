@@ -165,7 +165,7 @@ struct nq_handle {
     DevBuf<float> scan_box;           // merge loop: bounding boxes of the 64-position blocks (1024 x 8 floats)
     DevBuf<nq::MergeJob> d_jobs;      // merge jobs of the current call (1, or the whole batch on the first handle)
     long long merge_stats[16] = {0};
-    DevBuf<int> d_ints;               // [0] maxbins, [1] status
+    DevBuf<int> d_ints;               // [0] maxbins, [1] status, [8..71] occupied slots per 1024-slot slice
     DevBuf<int> heap;
     DevBuf<float> binf;               // f[4], cnt, err : 6 x 65536
     DevBuf<double> bind;              // d[4] : 4 x 65536
@@ -196,7 +196,7 @@ int use_device(nq_handle* h) {
         upload_tables(gamma, std::exp(1.5), std::exp(1.75), h->stream);
         NQ_HIP(h, hipGetLastError());
         NQ_HIP(h, h->d_scalars.reserve(40));
-        NQ_HIP(h, h->d_ints.reserve(4));
+        NQ_HIP(h, h->d_ints.reserve(8 + 64));
         NQ_HIP(h, h->d_bincache.reserve(65536));
         for (auto& e : h->ev) NQ_HIP(h, hipEventCreate(&e));
         h->tables_ready = true;
@@ -358,7 +358,7 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
     const int kind = h->kind;
     nq::Bins B = bins_of(h);
     int* d_maxbins = h->d_ints.p;
-    launch_compact(kind, d_hists, n_bands, B, d_maxbins, h->stream);
+    launch_compact(kind, d_hists, n_bands, B, d_maxbins, h->d_ints.p + 8, h->stream);
     int maxbins = 0;
     NQ_HIP(h, hipMemcpyAsync(&maxbins, d_maxbins, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -458,6 +458,10 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
     job->mj.heap = h->heap.p; job->mj.live3 = h->live3.p; job->mj.scan_f = h->scan_f.p; job->mj.scan_i = h->scan_i.p; job->mj.scan_box = h->scan_box.p;
     job->mj.stats = h->d_scalars.p + 4;
     job->plen = extbins > 0 ? nMaxColors : maxbins;
+    // the merge workgroup also fills the palette (P10)
+    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(job->plen, 2)));
+    NQ_HIP(h, hipMemsetAsync(h->d_ints.p + 1, 0, sizeof(int), h->stream));
+    job->mj.plen = job->plen; job->mj.palette = h->d_palette.p; job->mj.status = h->d_ints.p + 1;
     return NQ_OK;
 }
 
@@ -480,13 +484,11 @@ int merge_launch(nq_handle* owner, const PaletteJob* const* jobs, int n) {
     return NQ_OK;
 }
 
-// palette fill (P10) + read-back
+// read-back of the palette the merge workgroup wrote (P10)
 int palette_finish(nq_handle* h, const PaletteJob& job, uint32_t* out_palette, int32_t* out_K) {
     nq_params& p = h->params;
     const int plen = job.plen;
-    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(plen, 2)));
     int* d_status = h->d_ints.p + 1;
-    launch_palette_fill(h->kind, job.mj.B, job.mj.maxbins, plen, h->d_palette.p, d_status, h->stream);
     rec(h, 5);
     int status = 0;
     NQ_HIP(h, hipMemcpyAsync(out_palette, h->d_palette.p, plen * sizeof(int), hipMemcpyDeviceToHost, h->stream));

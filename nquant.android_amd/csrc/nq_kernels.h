@@ -99,7 +99,8 @@ void launch_distinct(const int* d_pixels, int64_t n, int transparentColor, unsig
 void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s);
 void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams& hp, const SortWorkspace& ws,
                       double* d_hist, hipStream_t s);
-void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, hipStream_t s);
+// d_blockcnt: int[64] scratch (occupied bins per 1024-bin slice)
+void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, int* d_blockcnt, hipStream_t s);
 void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s);
 void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, hipStream_t s);
 // One merge loop (P9).  heap: int[2*(65536+2)] (ids, then float keys); live3: int[3*65536] (two live lists + position index);
@@ -111,11 +112,11 @@ struct MergeJob {
     int* heap; int* live3; float* scan_f; int* scan_i;
     float* scan_box;            // float[1024 * 8]: bounding boxes of the 64-position blocks of the LAB scan arrays
     long long* stats;
+    int plen; int* palette; int* status;   // P10 runs at the end of the merge workgroup: palette[plen], status |= 1 where Java throws
 };
 // d_jobs: n jobs of one kind in device memory, one workgroup per job.  n_in_flight = merge loops expected to run at the same
 // time on the device (the whole batch): <= 256 -> 512-thread workgroups, one per CU; <= 512 -> 256 threads, two per CU;
 // more -> 128 threads, four per CU
 void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, hipStream_t s);
-void launch_palette_fill(int kind, const Bins& B, int maxbins, int plen, int* d_palette, int* d_status, hipStream_t s);
 
 } // namespace nq

@@ -173,9 +173,10 @@ void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams
     else
         hipLaunchKernelGGL(hist_segments_kernel<0>, dim3(65536 / 4), dim3(256), 0, s, ws.vals_b, ws.seg_start, ws.seg_end, d_hist);
 }
-void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, hipStream_t s) {
-    if (kind == 1) hipLaunchKernelGGL(compact_means_kernel<1>, dim3(1), dim3(1024), 0, s, d_hists, n_bands, B, d_maxbins);
-    else hipLaunchKernelGGL(compact_means_kernel<0>, dim3(1), dim3(1024), 0, s, d_hists, n_bands, B, d_maxbins);
+void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, int* d_blockcnt, hipStream_t s) {
+    hipLaunchKernelGGL(compact_count_kernel, dim3(64), dim3(1024), 0, s, d_hists, n_bands, d_blockcnt);
+    if (kind == 1) hipLaunchKernelGGL(compact_means_kernel<1>, dim3(64), dim3(1024), 0, s, d_hists, n_bands, B, d_blockcnt, d_maxbins);
+    else hipLaunchKernelGGL(compact_means_kernel<0>, dim3(64), dim3(1024), 0, s, d_hists, n_bands, B, d_blockcnt, d_maxbins);
 }
 void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s) {
     if (fn == 0 || maxbins <= 0) return;
@@ -209,10 +210,4 @@ void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, hipS
         else launch_merge_variant(m128::merge_kernel<0>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
     }
 }
-void launch_palette_fill(int kind, const Bins& B, int maxbins, int plen, int* d_palette, int* d_status, hipStream_t s) {
-    (void) hipMemsetAsync(d_status, 0, sizeof(int), s);
-    if (kind == 1) hipLaunchKernelGGL(palette_fill_kernel<1>, dim3(1), dim3(1024), 0, s, B, maxbins, plen, d_palette, d_status);
-    else hipLaunchKernelGGL(palette_fill_kernel<0>, dim3(1), dim3(1024), 0, s, B, maxbins, plen, d_palette, d_status);
-}
-
 } // namespace nq
