@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of BASELINE.json: Mpixels/s, 4096x4096 RGBA -> 256-colour PnnLAB + dither.
 
-One "step" = one batch (--batch, default 256) of distinct 4096x4096 ARGB images, already resident in HBM, each through the
+One "step" = one batch (--batch, default 1024 = 64 GiB of input) of distinct 4096x4096 ARGB images, already resident in HBM, each through the
 whole convert(256, dither=true): alpha pre-scan, histogram, find_nn, merge loop, palette fill, gilbert-curve error diffusion
 (PARALLEL_TILED).  The merge loop of one image is a sequential chain on one CU, so images are handed over in batches
-(nq_convert_batch_device): the merge loops of a batch run side by side, one workgroup each.
+(nq_convert_batch_device): the merge loops of a batch run side by side, one workgroup each (four per CU at this batch size).
+Device memory: batch x 160 MiB of pixel buffers (in, out, index) + 10 MiB of quantizer state per image.
 Multi-GPU (driver: torch.distributed.run, one rank per GPU): every rank converts its own batches (independent units,
 no data-path collective; RCCL only for the barrier / max-over-ranks of the time) -> "scaling": "weak".
 
@@ -73,18 +74,18 @@ def measured_traffic(w, h):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4, help="one step = one batch of --batch images through the whole hot path")
+    ap.add_argument("--steps", type=int, default=3, help="one step = one batch of --batch images through the whole hot path")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform"])
     ap.add_argument("--tile", type=int, default=0, help="tile side of the PARALLEL_TILED decomposition (0 = automatic)")
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="side of the CPU-baseline sample image (0 = skip)")
-    ap.add_argument("--batch", type=int, default=256,
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="side of the CPU-baseline sample image (0 = skip)")
+    ap.add_argument("--batch", type=int, default=1024,
                     help="images per step (distinct synthetic images, all resident in HBM): the merge loop of one image is a "
                          "sequential chain on one CU, a batch runs its merge loops side by side (nq_convert_batch_device)")
-    ap.add_argument("--concurrency", type=int, default=2,
-                    help="host threads / HIP streams a step's batch is split over, so that the per-pixel stages of one sub-batch "
-                         "overlap the merge loops of another")
+    ap.add_argument("--concurrency", type=int, default=1,
+                    help="host threads / HIP streams a step's batch is split over (measured: one call for the whole batch is best -- the "
+                         "library then runs 128-thread merge workgroups, four per CU, and the per-pixel stages have the chip to themselves)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,6 +110,13 @@ def main():
     W = H = args.size
     npx = W * H
     Bn = max(1, args.batch)
+    # every image of the batch is resident: 10 B/pixel of buffers + ~10 MiB of quantizer state, plus the per-pixel scratch of the
+    # batch (~20 B/pixel) and headroom; shrink the batch rather than run out of device memory
+    free_b, _total_b = torch.cuda.mem_get_info()
+    per_image = 10 * npx + (12 << 20)
+    fit = int((free_b - 24 * npx - (6 << 30)) // per_image)
+    if fit < Bn:
+        Bn = max(1, fit)
     T = max(1, min(args.concurrency, Bn))
     tile = args.tile
     if tile <= 0:      # the library's automatic rule (nq_set_tile): largest of 16, 8, 4 with >= 131072 tiles
