@@ -439,7 +439,7 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
     np.ratio = p.ratio; np.PR = p.PR; np.PG = p.PG; np.PB = p.PB; np.PA = p.PA;
     np.pgLessThanCoeff = p.PG < kCoeffs[0][1];
     rec(h, 2);
-    launch_find_nn_init(np, B, maxbins, h->stream);
+    launch_find_nn_init(np, B, maxbins, h->scan_box.p, h->stream);
     rec(h, 3);
     if (kind == NQ_KIND_LAB) {
         // NQ/PnnLABQuantizer.java:259-264: ratio retuned AFTER the initial pass

@@ -182,9 +182,13 @@ void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s) {
     if (fn == 0 || maxbins <= 0) return;
     hipLaunchKernelGGL(quanfn_kernel, dim3((maxbins + 255) / 256), dim3(256), 0, s, d_cnt, maxbins, fn);
 }
-void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, hipStream_t s) {
+void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, float* d_box, hipStream_t s) {
     if (maxbins <= 0) return;
-    if (np.kind == 1) hipLaunchKernelGGL(find_nn_init_lab_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
+    if (np.kind == 1) {
+        const int nblk = (maxbins + 63) / 64;
+        hipLaunchKernelGGL(init_boxes_kernel, dim3((nblk + 255) / 256), dim3(256), 0, s, B, maxbins, d_box);
+        hipLaunchKernelGGL(find_nn_init_lab_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins, (const float*) d_box);
+    }
     else hipLaunchKernelGGL(find_nn_init_kernel<0>, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
 }
 // one workgroup per job; the workgroup size follows the number of jobs in flight (nq_merge.inc)
