@@ -211,7 +211,7 @@ DevParams dev_params(const nq_handle* h, int K) {
     d.transparentColor = p.transparentColor; d.isNano = p.isNano;
     d.binKeyed = h->kind == NQ_KIND_LAB ? (p.isNano != 0) : !(p.weight > .015);
     d.nMaxColors = p.nMaxColors; d.rewriteA0 = p.nMaxColors <= 2 && p.nMaxColors > 0;
-    { const char* dbg = std::getenv("NQ_DEBUG_FLAGS"); d.pad = dbg ? std::atoi(dbg) : 0; }   // timing experiments only
+    d.pad = 0;
     d.PR = p.PR; d.PG = p.PG; d.PB = p.PB; d.PA = p.PA; d.ratio = p.ratio; d.weight = p.weight;
     return d;
 }

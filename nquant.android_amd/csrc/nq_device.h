@@ -601,7 +601,6 @@ __device__ __forceinline__ int closest_rgb(LookupCtx& cx, int c, int pos) {
 __device__ __forceinline__ int closest_lab(LookupCtx& cx, int c) {
     const DevParams& P = *cx.P;
     if (c_alpha(c) <= 0xF) return nearest_cached(cx, c);
-    if (P.pad & 4) return (c >> 3) & 0xFF;               // TIMING EXPERIMENT ONLY (bit 2): no closest scan
     int closest[4];
     closest_tuple_lab(P, cx.pal, c, closest, cx.lists);
     int idx = 1;
@@ -610,7 +609,6 @@ __device__ __forceinline__ int closest_lab(LookupCtx& cx, int c) {
         idx = 0;
     const int MAX_ERR = P.K;
     if (closest[idx + 2] >= MAX_ERR || closest[idx] == 0 || c_alpha(cx.pal.argb[closest[idx]]) < c_alpha(c)) {
-        if (P.pad & 1) return closest[idx];          // TIMING EXPERIMENT ONLY (NQ_DEBUG_FLAGS bit 0): no nearest fallback
         return nearest_cached(cx, c);
     }
     return closest[idx];

@@ -10,7 +10,7 @@ for tile in ((16,16),(8,8),(8,4)):
     q.set_tile(*tile)
     for it in range(2):
         torch.cuda.synchronize(); t=time.perf_counter(); q.dither_device(d_in.data_ptr(),pal,True,d_out.data_ptr(),d_idx.data_ptr()); torch.cuda.synchronize(); dt=time.perf_counter()-t
-    print(os.environ.get("NQ_DEBUG_FLAGS","0"),tile,"dither total ms %.2f"%(dt*1e3), flush=True)
+    print(tile,"dither total ms %.2f"%(dt*1e3), flush=True)
 
 c,n=q.list_counts()
 import numpy as np
