@@ -119,6 +119,15 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
                             uint32_t* const* d_out_argb, uint16_t* const* d_out_index,
                             uint32_t* out_palettes, int32_t palette_stride, int32_t* out_K);
 
+/* same with HOST buffers (what a JNI shim holds): host arrays of n host pointers.  Uploads run ahead of the per-image stages and
+ * results are copied back while the next image is dithered, on a second stream; only the inputs (4 B/pixel) stay resident for
+ * the batch.  Page-locked buffers (direct ByteBuffers registered with hipHostRegister, hipHostMalloc) make the copies
+ * asynchronous; pageable memory works, the copies then block the calling thread.  out_index / out_index[i] may be NULL. */
+int nq_convert_batch(nq_handle* const* hs, int n, const uint32_t* const* argb, const int32_t* widths,
+                     const int32_t* heights, int nMaxColors, int dither, const int64_t* rng_seeds, int mode,
+                     uint32_t* const* out_argb, uint16_t* const* out_index,
+                     uint32_t* out_palettes, int32_t palette_stride, int32_t* out_K);
+
 /* ---- Integer[] pnnquan(int[] pixels, int nMaxColors) incl. the alpha pre-scan of convert()
  *      (NQ/PnnQuantizer.java:410-436,134-267; NQ/PnnLABQuantizer.java:131-327) ---- */
 int nq_pnnquan(nq_handle* h, const uint32_t* argb, int width, int height, int nMaxColors,

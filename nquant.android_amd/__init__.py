@@ -6,9 +6,9 @@ Python host-side mirror used by the tests and bench.py.  It never imports the CP
 constructing a quantizer without a usable HIP device raises."""
 from .host import (NQ_KIND_RGB, NQ_KIND_LAB, MODE_REFERENCE_SEQUENTIAL, MODE_PARALLEL_TILED, MODE_LOOKUP_ONLY,
                    NqError, Params, PnnQuantizer, PnnLABQuantizer, QuantizedImage, load_library, library_path,
-                   abi_symbols, convert_batch_device)
+                   abi_symbols, convert_batch_device, convert_batch_host)
 from .build import build as build_library
 
 __all__ = ["NQ_KIND_RGB", "NQ_KIND_LAB", "MODE_REFERENCE_SEQUENTIAL", "MODE_PARALLEL_TILED", "MODE_LOOKUP_ONLY",
            "NqError", "Params", "PnnQuantizer", "PnnLABQuantizer", "QuantizedImage", "load_library", "library_path",
-           "abi_symbols", "build_library", "convert_batch_device"]
+           "abi_symbols", "build_library", "convert_batch_device", "convert_batch_host"]

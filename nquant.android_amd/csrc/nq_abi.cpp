@@ -164,6 +164,9 @@ struct nq_handle {
     DevBuf<int> scan_i;
     DevBuf<float> scan_box;           // merge loop: bounding boxes of the 64-position blocks (1024 x 8 floats)
     DevBuf<nq::MergeJob> d_jobs;      // merge jobs of the current call (1, or the whole batch on the first handle)
+    DevBuf<int> ring_argb[3];         // nq_convert_batch: device output ring (results leave for the host while the next image runs)
+    DevBuf<unsigned short> ring_index[3];
+    hipStream_t copy_stream = nullptr;
     long long merge_stats[16] = {0};
     DevBuf<int> d_ints;               // [0] maxbins, [1] status, [8..71] occupied slots per 1024-slot slice
     DevBuf<int> heap;
@@ -176,6 +179,7 @@ struct nq_handle {
     ~nq_handle() {
         for (auto& kv : paths) (void) hipFree(kv.second);
         for (auto& e : ev) if (e) (void) hipEventDestroy(e);
+        if (copy_stream) (void) hipStreamDestroy(copy_stream);
     }
 };
 
@@ -860,6 +864,100 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
         if (rc) return fail_from(hs[i], rc);
     }
     NQ_HIP(h0, hipStreamSynchronize(h0->stream));
+    for (int i = 0; i < n; ++i) finish_timing(hs[i]);
+    return NQ_OK;
+}
+
+// Host-buffer form of the batch: uploads run ahead of the per-image stages on a copy stream, every image's result is copied
+// back while the next image is dithered (a ring of three device output buffers), so only the inputs (4 B/pixel) and the
+// quantizer state stay resident for the whole batch.
+int nq_convert_batch(nq_handle* const* hs, int n, const uint32_t* const* argb, const int32_t* widths, const int32_t* heights,
+                     int nMaxColors, int dither, const int64_t* rng_seeds, int mode,
+                     uint32_t* const* out_argb, uint16_t* const* out_index,
+                     uint32_t* out_palettes, int32_t palette_stride, int32_t* out_K) {
+    if (!hs || n <= 0 || !hs[0]) return NQ_ERR_INVALID;
+    nq_handle* h0 = hs[0];
+    if (!argb || !widths || !heights || !rng_seeds || !out_argb || !out_palettes || !out_K)
+        NQ_FAIL(h0, NQ_ERR_INVALID, "bad argument");
+    if (palette_stride < std::max(nMaxColors, 2)) NQ_FAIL(h0, NQ_ERR_INVALID, "palette_stride < max(nMaxColors, 2)");
+    size_t max_px = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i] || !argb[i] || !out_argb[i] || widths[i] <= 0 || heights[i] <= 0) NQ_FAIL(h0, NQ_ERR_INVALID, "bad argument for image %d", i);
+        if (hs[i]->device != h0->device) NQ_FAIL(h0, NQ_ERR_INVALID, "handles of a batch must share one device");
+        for (int j = 0; j < i; ++j) if (hs[j] == hs[i]) NQ_FAIL(h0, NQ_ERR_INVALID, "a handle appears twice in the batch");
+        max_px = std::max(max_px, (size_t) widths[i] * heights[i]);
+    }
+    struct Restore {
+        nq_handle* const* hs; int n; std::vector<hipStream_t> streams; std::vector<hipEvent_t> events;
+        ~Restore() {
+            for (int i = 0; i < n; ++i) { hs[i]->stream = streams[i]; hs[i]->sc = &hs[i]->own; }
+            for (hipEvent_t e : events) (void) hipEventDestroy(e);
+        }
+    } restore{hs, n, {}, {}};
+    for (int i = 0; i < n; ++i) restore.streams.push_back(hs[i]->stream);
+    auto fail_from = [&](nq_handle* h, int rc) { if (h != h0) h0->err = h->err; return rc; };
+    for (int i = 0; i < n; ++i) {
+        int rc = use_device(hs[i]);
+        if (rc) return fail_from(hs[i], rc);
+        if (i) NQ_HIP(h0, hipStreamSynchronize(hs[i]->stream));
+        NQ_HIP(h0, hs[i]->d_in.reserve((size_t) widths[i] * heights[i]));
+        hs[i]->stream = h0->stream; hs[i]->sc = &h0->own;
+    }
+    constexpr int RING = 3;
+    for (int r = 0; r < RING; ++r) { NQ_HIP(h0, h0->ring_argb[r].reserve(max_px)); NQ_HIP(h0, h0->ring_index[r].reserve(max_px)); }
+    if (!h0->copy_stream) NQ_HIP(h0, hipStreamCreateWithFlags(&h0->copy_stream, hipStreamNonBlocking));
+    hipStream_t cs = h0->copy_stream;
+    auto new_event = [&](hipEvent_t* e) -> hipError_t {
+        hipError_t rc = hipEventCreateWithFlags(e, hipEventDisableTiming);
+        if (rc == hipSuccess) restore.events.push_back(*e);
+        return rc;
+    };
+    std::vector<hipEvent_t> ev_up(n), ev_done(n), ev_dl(n);
+    for (int i = 0; i < n; ++i) { NQ_HIP(h0, new_event(&ev_up[i])); NQ_HIP(h0, new_event(&ev_done[i])); NQ_HIP(h0, new_event(&ev_dl[i])); }
+    int uploaded = 0;
+    auto upload_until = [&](int last) -> int {          // asynchronous when the caller's buffers are page-locked
+        for (; uploaded <= last && uploaded < n; ++uploaded) {
+            const int i = uploaded;
+            NQ_HIP(h0, hipMemcpyAsync(hs[i]->d_in.p, argb[i], (size_t) widths[i] * heights[i] * sizeof(int), hipMemcpyHostToDevice, cs));
+            NQ_HIP(h0, hipEventRecord(ev_up[i], cs));
+        }
+        return NQ_OK;
+    };
+    std::vector<PaletteJob> jobs(n);
+    std::vector<const PaletteJob*> jp(n);
+    for (int i = 0; i < n; ++i) {
+        int rc = upload_until(i + 2);
+        if (rc) return rc;
+        NQ_HIP(h0, hipStreamWaitEvent(h0->stream, ev_up[i], 0));
+        rc = pnnquan_prepare(hs[i], (const uint32_t*) hs[i]->d_in.p, widths[i], heights[i], nMaxColors,
+                             out_palettes + (size_t) i * palette_stride, out_K + i, &jobs[i]);
+        if (rc) return fail_from(hs[i], rc);
+        jp[i] = &jobs[i];
+    }
+    int rc = merge_launch(h0, jp.data(), n);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) if (jobs[i].merge) rec(hs[i], 4);
+    for (int i = 0; i < n; ++i) {
+        uint32_t* pal = out_palettes + (size_t) i * palette_stride;
+        if (jobs[i].merge) {
+            rc = palette_finish(hs[i], jobs[i], pal, out_K + i);
+            if (rc) return fail_from(hs[i], rc);
+        }
+        const int r = i % RING;
+        if (i >= RING) NQ_HIP(h0, hipStreamWaitEvent(h0->stream, ev_dl[i - RING], 0));     // the slot's previous result has left
+        rc = dither_device(hs[i], (const uint32_t*) hs[i]->d_in.p, widths[i], heights[i], pal, out_K[i], dither, rng_seeds[i], mode,
+                           (uint32_t*) h0->ring_argb[r].p, h0->ring_index[r].p);
+        if (rc) return fail_from(hs[i], rc);
+        NQ_HIP(h0, hipEventRecord(ev_done[i], h0->stream));
+        NQ_HIP(h0, hipStreamWaitEvent(cs, ev_done[i], 0));
+        const size_t px = (size_t) widths[i] * heights[i];
+        NQ_HIP(h0, hipMemcpyAsync(out_argb[i], h0->ring_argb[r].p, px * sizeof(int), hipMemcpyDeviceToHost, cs));
+        if (out_index && out_index[i])
+            NQ_HIP(h0, hipMemcpyAsync(out_index[i], h0->ring_index[r].p, px * sizeof(uint16_t), hipMemcpyDeviceToHost, cs));
+        NQ_HIP(h0, hipEventRecord(ev_dl[i], cs));
+    }
+    NQ_HIP(h0, hipStreamSynchronize(h0->stream));
+    NQ_HIP(h0, hipStreamSynchronize(cs));
     for (int i = 0; i < n; ++i) finish_timing(hs[i]);
     return NQ_OK;
 }

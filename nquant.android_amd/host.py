@@ -20,7 +20,7 @@ _LIB = None
 
 ABI_SYMBOLS = [
     "nq_abi_version", "nq_create", "nq_destroy", "nq_last_error", "nq_set_stream", "nq_set_tile", "nq_set_option", "nq_get_list_counts", "nq_get_params",
-    "nq_set_params", "nq_convert", "nq_convert_device", "nq_convert_batch_device", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
+    "nq_set_params", "nq_convert", "nq_convert_device", "nq_convert_batch_device", "nq_convert_batch", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
     "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_get_stage_ms", "nq_get_merge_stats",
 ]
@@ -100,6 +100,7 @@ def load_library():
     L.nq_convert.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, C.POINTER(C.c_int32)]
     L.nq_convert_device.argtypes = [vp, vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, C.POINTER(C.c_int32)]
     L.nq_convert_batch_device.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp]
+    L.nq_convert_batch.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp]
     L.nq_pnnquan.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(C.c_int32)]
     L.nq_pnnquan_device.argtypes = [vp, vp, i32, i32, i32, vp, C.POINTER(C.c_int32)]
     L.nq_dither.argtypes = [vp, vp, i32, i32, vp, i32, i32, i64, i32, vp, vp]
@@ -282,7 +283,14 @@ class PnnQuantizer:
                                              C.c_void_p(d_out_index or None)))
 
 
-def convert_batch_device(quantizers, d_pixels, nMaxColors, dither, d_out_argb, d_out_index=None, mode=None, seeds=None):
+def convert_batch_host(quantizers, pixels, nMaxColors, dither, out_argb, out_index=None, mode=None, seeds=None):
+    """nq_convert_batch: like convert_batch_device with HOST addresses (ints) of the pixel / output buffers -- uploads and
+    read-backs overlap the per-image stages (fully when the buffers are page-locked)."""
+    return convert_batch_device(quantizers, pixels, nMaxColors, dither, out_argb, out_index, mode, seeds, _entry="nq_convert_batch")
+
+
+def convert_batch_device(quantizers, d_pixels, nMaxColors, dither, d_out_argb, d_out_index=None, mode=None, seeds=None,
+                         _entry="nq_convert_batch_device"):
     """nq_convert_batch_device: convert() of several quantizer objects in one call -- their merge loops run side by side in one
     launch.  `quantizers[i].width/height` describe image i, `d_pixels[i]`, `d_out_argb[i]`, `d_out_index[i]` are HIP device
     addresses.  Returns the list of palettes; results equal len(quantizers) separate convert_device calls."""
@@ -300,7 +308,7 @@ def convert_batch_device(quantizers, d_pixels, nMaxColors, dither, d_out_argb, d
     stride = max(int(nMaxColors), 2)
     pal = np.zeros((n, stride), np.int32)
     K = np.zeros(n, np.int32)
-    q0._check(q0._L.nq_convert_batch_device(hs, n, src, widths.ctypes.data, heights.ctypes.data, int(nMaxColors), int(bool(dither)),
+    q0._check(getattr(q0._L, _entry)(hs, n, src, widths.ctypes.data, heights.ctypes.data, int(nMaxColors), int(bool(dither)),
                                             sd.ctypes.data, int(q0.mode if mode is None else mode), dst, idx, pal.ctypes.data,
                                             stride, K.ctypes.data))
     return [pal[i, :K[i]].copy() for i in range(n)]

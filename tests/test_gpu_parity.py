@@ -392,3 +392,38 @@ def test_merge_loop_variants_agree_with_oracle(nq, oracle, threads, monkeypatch)
         gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=TILED, seed=1)
         got = gq.pnnquan(K)
         assert len(got) == len(want) and (got != want).sum() == 0, (threads, kind)
+
+
+def test_convert_batch_host_equals_device_batch(nq):
+    """nq_convert_batch (host buffers, uploads / read-backs overlapped on a copy stream, ring of three device output buffers) ==
+    nq_convert_batch_device, with page-locked and with pageable host memory; more images than ring slots."""
+    import torch
+    imgs = [(1, synth.gradient_noise(96 + 8 * i, 80, 120 + i)) for i in range(5)] + [(0, synth.uniform_rgb(64, 72, 130))]
+    cls = {0: nq.PnnQuantizer, 1: nq.PnnLABQuantizer}
+
+    def fresh():
+        qs = []
+        for i, (kind, im) in enumerate(imgs):
+            q = cls[kind](np.zeros((1, 1), np.int32), mode=TILED, seed=11 + i, tile=(16, 16))
+            q.height, q.width = im.shape
+            qs.append(q)
+        return qs
+
+    d_in = [torch.from_numpy(np.ascontiguousarray(im).reshape(-1)).cuda() for _, im in imgs]
+    d_out = [torch.empty_like(d) for d in d_in]
+    d_idx = [torch.empty(d.numel(), dtype=torch.int16, device="cuda") for d in d_in]
+    want_pal = nq.convert_batch_device(fresh(), [d.data_ptr() for d in d_in], 256, True, [o.data_ptr() for o in d_out],
+                                       [x.data_ptr() for x in d_idx])
+    torch.cuda.synchronize()
+    for pinned in (True, False):
+        h_in = [torch.from_numpy(np.ascontiguousarray(im).reshape(-1).copy()) for _, im in imgs]
+        h_out = [torch.zeros(t.numel(), dtype=torch.int32) for t in h_in]
+        h_idx = [torch.zeros(t.numel(), dtype=torch.int16) for t in h_in]
+        if pinned:
+            h_in = [t.pin_memory() for t in h_in]; h_out = [t.pin_memory() for t in h_out]; h_idx = [t.pin_memory() for t in h_idx]
+        got_pal = nq.convert_batch_host(fresh(), [t.data_ptr() for t in h_in], 256, True, [t.data_ptr() for t in h_out],
+                                        [t.data_ptr() for t in h_idx])
+        for i in range(len(imgs)):
+            assert (got_pal[i] != want_pal[i]).sum() == 0, (pinned, i)
+            assert (h_out[i].numpy() != d_out[i].cpu().numpy()).sum() == 0, (pinned, i)
+            assert (h_idx[i].numpy() != d_idx[i].cpu().numpy()).sum() == 0, (pinned, i)
