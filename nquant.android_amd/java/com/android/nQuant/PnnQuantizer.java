@@ -51,6 +51,27 @@ public class PnnQuantizer {
 		return handle != 0 && nqHasAlpha(handle);
 	}
 
+	/** convert() of many quantizer objects in one call (nq_convert_batch): the merge loops of all images run side by side on
+	 *  the GPU.  in[i] / out[i] are DIRECT buffers of width*height ints (page-lock them for fully overlapped copies);
+	 *  returns the palettes. Results equal quantizers[i].convert(nMaxColors, dither) with the same seed. */
+	public static int[][] convertBatch(PnnQuantizer[] quantizers, java.nio.IntBuffer[] in, java.nio.IntBuffer[] out,
+			int nMaxColors, boolean dither) {
+		long[] handles = new long[quantizers.length], seeds = new long[quantizers.length];
+		int[] widths = new int[quantizers.length], heights = new int[quantizers.length];
+		for (int i = 0; i < quantizers.length; ++i) {
+			PnnQuantizer q = quantizers[i];
+			if (q.handle == 0)
+				q.handle = nqCreate(q.kind(), 0);
+			handles[i] = q.handle; seeds[i] = q.seed; widths[i] = q.width; heights[i] = q.height;
+		}
+		int[][] palettes = nqConvertBatch(handles, in, widths, heights, nMaxColors, dither, seeds, quantizers[0].mode, out);
+		for (int i = 0; i < quantizers.length; ++i)
+			quantizers[i].palette = palettes[i];
+		return palettes;
+	}
+	private static native int[][] nqConvertBatch(long[] handles, java.nio.IntBuffer[] in, int[] widths, int[] heights,
+			int nMaxColors, boolean dither, long[] seeds, int mode, java.nio.IntBuffer[] out);
+
 	@Override
 	protected void finalize() throws Throwable {
 		if (handle != 0) { nqDestroy(handle); handle = 0; }

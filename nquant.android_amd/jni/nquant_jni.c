@@ -8,6 +8,7 @@
  */
 #include <jni.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "nquant_abi.h"
 
 static void throw_rt(JNIEnv* env, const char* msg) {
@@ -48,4 +49,43 @@ JNIEXPORT jboolean JNICALL Java_com_android_nQuant_PnnQuantizer_nqHasAlpha(JNIEn
     nq_params p;
     if (nq_get_params((nq_handle*) (intptr_t) hh, &p) != NQ_OK) return JNI_FALSE;
     return p.transparentPixelIndex > -1 ? JNI_TRUE : JNI_FALSE;               /* NQ/PnnQuantizer.java:458-460 */
+}
+
+/* convertBatch(): direct IntBuffers in, direct IntBuffers out -> nq_convert_batch (uploads / read-backs overlapped; all merge
+ * loops in one launch).  Returns int[n][] palettes. */
+JNIEXPORT jobjectArray JNICALL Java_com_android_nQuant_PnnQuantizer_nqConvertBatch(JNIEnv* env, jclass c, jlongArray handles,
+        jobjectArray in, jintArray widths, jintArray heights, jint nMaxColors, jboolean dither, jlongArray seeds, jint mode,
+        jobjectArray out) {
+    const jsize n = (*env)->GetArrayLength(env, handles);
+    const int stride = nMaxColors > 2 ? nMaxColors : 2;
+    nq_handle** hs = malloc(sizeof(*hs) * n);
+    const uint32_t** src = malloc(sizeof(*src) * n);
+    uint32_t** dst = malloc(sizeof(*dst) * n);
+    uint32_t* palettes = malloc(sizeof(uint32_t) * (size_t) stride * n);
+    int32_t* K = malloc(sizeof(int32_t) * n);
+    jlong* hh = (*env)->GetLongArrayElements(env, handles, NULL);
+    jlong* sd = (*env)->GetLongArrayElements(env, seeds, NULL);
+    jint* w = (*env)->GetIntArrayElements(env, widths, NULL);
+    jint* hg = (*env)->GetIntArrayElements(env, heights, NULL);
+    for (jsize i = 0; i < n; ++i) {
+        hs[i] = (nq_handle*) (intptr_t) hh[i];
+        src[i] = (const uint32_t*) (*env)->GetDirectBufferAddress(env, (*env)->GetObjectArrayElement(env, in, i));
+        dst[i] = (uint32_t*) (*env)->GetDirectBufferAddress(env, (*env)->GetObjectArrayElement(env, out, i));
+    }
+    const int rc = nq_convert_batch(hs, n, src, (const int32_t*) w, (const int32_t*) hg, nMaxColors, dither ? 1 : 0,
+                                    (const int64_t*) sd, mode, dst, NULL, palettes, stride, K);
+    jobjectArray result = NULL;
+    if (rc != NQ_OK) throw_rt(env, nq_last_error(hs[0]));
+    else {
+        result = (*env)->NewObjectArray(env, n, (*env)->FindClass(env, "[I"), NULL);
+        for (jsize i = 0; i < n; ++i) {
+            jintArray pal = (*env)->NewIntArray(env, K[i]);
+            (*env)->SetIntArrayRegion(env, pal, 0, K[i], (const jint*) (palettes + (size_t) i * stride));
+            (*env)->SetObjectArrayElement(env, result, i, pal);
+        }
+    }
+    (*env)->ReleaseIntArrayElements(env, heights, hg, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, widths, w, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, seeds, sd, JNI_ABORT); (*env)->ReleaseLongArrayElements(env, handles, hh, JNI_ABORT);
+    free(K); free(palettes); free(dst); free(src); free(hs);
+    return result;
 }
