@@ -27,6 +27,22 @@ CASES = {
 }
 
 
+# palette only: 64 309 occupied bins (uniform random colours), the size at which the merge loop's LDS mirrors of the heap and of
+# mtm are too small in every workgroup variant and all 1005 position blocks exist
+PALETTE_CASES = {
+    "lab256_palette_uniform_512x512": dict(kind=1, K=256, img=lambda: synth.uniform_rgb(512, 512, 7)),
+}
+
+
+def run_palette_case(c):
+    q = O.OracleQuantizer(c["kind"], c["img"]())
+    q.prescan(c["K"])
+    pal = q.pnnquan(c["K"])
+    p = q.params
+    return dict(palette=pal, scalars=np.array([p.maxbins, p.isNano, p.texicab, p.quan_rt], np.int64),
+                doubles=np.array([p.ratio, p.weight], np.float64))
+
+
 def run_case(c):
     img = c["img"]()
     q = O.OracleQuantizer(c["kind"], img, seed=c["seed"])
@@ -46,3 +62,7 @@ if __name__ == "__main__":
         r = run_case(c)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)
         print(name, "K", len(r["palette"]), "maxbins", int(r["scalars"][6]))
+    for name, c in PALETTE_CASES.items():
+        r = run_palette_case(c)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)
+        print(name, "K", len(r["palette"]), "maxbins", int(r["scalars"][0]))

@@ -38,3 +38,27 @@ def test_gpu_reproduces_golden(nq, name):
     argb, idx = q.dither(pal, c["dither"])
     assert (idx == want["index"]).all()
     assert (argb == want["argb"]).all()
+
+
+@pytest.mark.parametrize("name", sorted(mg.PALETTE_CASES))
+def test_oracle_reproduces_golden_palette(name):
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    got = mg.run_palette_case(mg.PALETTE_CASES[name])
+    for k in ("palette", "scalars", "doubles"):
+        assert (got[k] == want[k]).all(), (name, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [512, 256, 128])
+@pytest.mark.parametrize("name", sorted(mg.PALETTE_CASES))
+def test_gpu_reproduces_golden_palette_every_merge_variant(nq, name, threads, monkeypatch):
+    """~64k bins: beyond the LDS mirrors of every merge-workgroup variant (csrc/nq_merge.inc), all 1005 position blocks in use."""
+    monkeypatch.setenv("NQ_MERGE_THREADS", str(threads))
+    c = mg.PALETTE_CASES[name]
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    q = (nq.PnnLABQuantizer if c["kind"] else nq.PnnQuantizer)(c["img"](), mode=nq.MODE_PARALLEL_TILED, seed=1)
+    pal = q.pnnquan(c["K"])
+    assert len(pal) == len(want["palette"]) and (pal == want["palette"]).all()
+    p = q.params
+    assert [p.maxbins, p.isNano, p.texicab, p.quan_rt] == list(want["scalars"])
+    assert (np.array([p.ratio, p.weight]) == want["doubles"]).all()
