@@ -1,0 +1,68 @@
+"""Randomised GPU-vs-oracle parity sweep (palette + scalars, tiled dither, lookups) over image kinds, sizes, K and flags.
+python tools/fuzz_parity.py [seconds] [seed] [big]  -- prints every mismatch and a summary; exit code 1 on any mismatch."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib
+import nquant.android_amd as nq
+from nquant.android_amd import synth
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"      # 160..360 pixels a side (up to ~60k bins), palette + scalars only
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+Ks = [3, 4, 5, 8, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256]
+t_end = time.time() + budget
+n_cases = n_bad = 0
+while time.time() < t_end:
+    kind = int(rng.integers(0, 2))
+    w, h = (int(rng.integers(160, 360)), int(rng.integers(160, 360))) if BIG else (int(rng.integers(17, 150)), int(rng.integers(17, 150)))
+    seed = int(rng.integers(1, 1 << 30))
+    gen = int(rng.integers(0, 5))
+    if gen == 0: img = synth.uniform_rgb(w, h, seed)
+    elif gen == 1: img = synth.gradient_noise(w, h, seed, noise=int(rng.integers(0, 64)))
+    elif gen == 2: img = synth.few_colors(w, h, seed, int(rng.integers(2, 600)))
+    elif gen == 3: img = synth.with_alpha(synth.gradient_noise(w, h, seed), seed, p_transparent=float(rng.random() * 0.05), p_semi=float(rng.random() * 0.2))
+    else: img = synth.with_alpha(synth.few_colors(w, h, seed, int(rng.integers(2, 300))), seed)
+    K = int(Ks[rng.integers(0, len(Ks))])
+    dither = bool(rng.integers(0, 2))
+    tile = (int(rng.choice([4, 8, 16])),) * 2
+    rseed = int(rng.integers(0, 1 << 20))
+    tag = "kind %d %dx%d gen %d seed %d K %d dither %d tile %d" % (kind, w, h, gen, seed, K, dither, tile[0])
+    try:
+        oq = oracle_lib.OracleQuantizer(kind, img, seed=rseed)
+        oq.prescan(K)
+        want_pal = oq.pnnquan(K)
+        gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=nq.MODE_PARALLEL_TILED, seed=rseed, tile=tile)
+        got_pal = gq.pnnquan(K)
+        n_cases += 1
+        if len(got_pal) != len(want_pal) or (got_pal != want_pal).any():
+            n_bad += 1; print("PALETTE MISMATCH:", tag, flush=True); continue
+        po, pg = oq.params, gq.params
+        for f in ("hasSemiTransparency", "transparentPixelIndex", "transparentColor", "isNano", "texicab", "quan_rt", "maxbins",
+                  "PR", "PG", "PB", "PA", "ratio", "weight"):
+            if getattr(po, f) != getattr(pg, f):
+                n_bad += 1; print("PARAM MISMATCH:", f, tag, flush=True)
+        if BIG:
+            print("ok", tag, "maxbins", po.maxbins, flush=True)
+            continue
+        oq.set_seed(rseed)
+        want_argb, want_idx = oq.dither(want_pal, dither, tile=tile)
+        if kind == 1 and not dither and len(want_pal) > 32:
+            p = gq.params; p.distinctColors = oq.params.distinctColors; gq.set_params(p)
+        got_argb, got_idx = gq.dither(got_pal, dither)
+        if (got_idx.astype(np.int32) != want_idx).any() or (got_argb != want_argb).any():
+            n_bad += 1; print("DITHER MISMATCH: %d px" % int((got_idx.astype(np.int32) != want_idx).sum()), tag, flush=True)
+        cols = img.reshape(-1)[: 4096]
+        if (gq.nearestColorIndex(got_pal, cols) != oq.nearest_index(want_pal, cols)).any():
+            n_bad += 1; print("NEAREST MISMATCH:", tag, flush=True)
+        if (gq.closestTuple(got_pal, cols) != oq.closest_tuple(want_pal, cols)).any():
+            n_bad += 1; print("CLOSEST MISMATCH:", tag, flush=True)
+    except nq.NqError as e:
+        if e.status in (-3, -4):       # UNSUPPORTED / REFERENCE_THROWS are legitimate outcomes
+            continue
+        n_bad += 1; print("ERROR:", e, tag, flush=True)
+    if n_cases % 25 == 0:
+        print("... %d cases, %d mismatches" % (n_cases, n_bad), flush=True)
+print("fuzz: %d cases, %d mismatches" % (n_cases, n_bad))
+sys.exit(1 if n_bad else 0)
