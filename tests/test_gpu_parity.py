@@ -427,3 +427,21 @@ def test_convert_batch_host_equals_device_batch(nq):
             assert (got_pal[i] != want_pal[i]).sum() == 0, (pinned, i)
             assert (h_out[i].numpy() != d_out[i].cpu().numpy()).sum() == 0, (pinned, i)
             assert (h_idx[i].numpy() != d_idx[i].cpu().numpy()).sum() == 0, (pinned, i)
+
+
+@pytest.mark.parametrize("kind,K,dither,alpha", [(0, 2, True, False), (0, 2, False, True), (1, 2, True, True), (1, 2, False, False),
+                                                 (1, 1, True, False), (0, 16, False, False), (1, 8, True, True), (0, 300, True, False)])
+def test_whole_convert_sequential_equals_oracle_convert(nq, oracle, kind, K, dither, alpha):
+    """convert(n, dither) end to end in REFERENCE_SEQUENTIAL mode == the oracle's convert(), including nMaxColors <= 2 (fixed
+    two-colour palette, alpha-0 pixels read as the transparent colour, NQ/PnnQuantizer.java:424,441-452) and RGB K > 256."""
+    img = synth.gradient_noise(56, 44, 140 + K)
+    if alpha:
+        img = synth.with_alpha(img, 141 + K)
+    seed = 9
+    oq = oracle.OracleQuantizer(kind, img, seed=seed)
+    want_argb, want_idx, want_pal = oq.convert(K, dither)
+    gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=SEQ, seed=seed)
+    out = gq.convert(K, dither)
+    assert len(out.palette) == len(want_pal) and (out.palette != want_pal).sum() == 0
+    assert (out.argb != want_argb).sum() == 0
+    assert (out.index.astype(np.int32) != want_idx).sum() == 0
