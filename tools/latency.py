@@ -1,4 +1,5 @@
-"""Single-convert latency and merge-loop counters on the bench image (4096^2 gradient+noise, LAB, 256 colours)."""
+"""Single-convert latency and merge-loop counters on the bench image (4096^2 gradient+noise, LAB, 256 colours).
+python tools/latency.py [side] [kind 0|1] [uniform]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -6,7 +7,7 @@ import nquant.android_amd as nq
 from nquant.android_amd import synth
 W = H = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-d_in = synth.gradient_noise_torch(W, H, 3)
+d_in = synth.gradient_noise_torch(W, H, 3) if (len(sys.argv) <= 3 or sys.argv[3] != "uniform") else torch.from_numpy(synth.uniform_rgb(W, H, 3).reshape(-1)).cuda()
 out = torch.empty_like(d_in); idx = torch.empty(W * H, dtype=torch.int16, device="cuda")
 q = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(np.zeros((1, 1), np.int32), mode=1, seed=3)
 q.width, q.height = W, H
