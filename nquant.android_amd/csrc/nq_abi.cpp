@@ -240,14 +240,16 @@ int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
         if (P.K < 3) pr = pg = pb = pa = 1;
         wR = pr; wG = pg; wB = pb; wA = P.hasSemi ? pa : 0.0;
     }
-    const bool nearest = h->kind == NQ_KIND_LAB && P.K > 32 && !P.hasSemi;
-    if (nearest && !h->sc->cell_box_ready) {
+    // nearestColorIndex lists: LAB for the K > 32 metric; RGB for opaque images (no transparent colour: the scan starts at 0)
+    const bool nearest = h->kind == NQ_KIND_LAB ? (P.K > 32 && !P.hasSemi) : (!P.hasSemi && !P.hasAlpha);
+    if (nearest && h->kind == NQ_KIND_LAB && !h->sc->cell_box_ready) {
         NQ_HIP(h, h->sc->cell_box.reserve((size_t) 65536 * 6));
         launch_cell_lab_box(h->sc->cell_box.p, h->stream);
         h->sc->cell_box_ready = true;
     }
     launch_build_lists(P, h->d_palette.p, wA, wR, wG, wB, nearest, h->sc->cell_box.p, base, base + 2 * LB, base + LB, base + 2 * LB + 65536, h->stream);
-    out->closest = base; out->closestCount = base + 2 * LB;
+    // (a negative ratio makes the closest error non-monotone in its terms: the list argument does not hold, full scans)
+    if (!(h->kind == NQ_KIND_LAB && P.ratio < 0)) { out->closest = base; out->closestCount = base + 2 * LB; }
     if (nearest) { out->nearest = base + LB; out->nearestCount = base + 2 * LB + 65536; }
     return NQ_OK;
 }

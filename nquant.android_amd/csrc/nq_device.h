@@ -354,7 +354,7 @@ __device__ __forceinline__ CellList load_cell_list(const unsigned char* __restri
 
 // ---- nearestColorIndex, cache-miss semantics ----------------------------------------------------
 // RGB: NQ/PnnQuantizer.java:276-310
-__device__ __forceinline__ int nearest_rgb(const DevParams& P, const PalView& pal, int c) {
+__device__ __forceinline__ int nearest_rgb(const DevParams& P, const PalView& pal, int c, const CellLists* lists = nullptr) {
     const int K = P.K;
     int k = 0;
     if (c_alpha(c) <= 0xF) c = P.transparentColor;
@@ -363,6 +363,24 @@ __device__ __forceinline__ int nearest_rgb(const DevParams& P, const PalView& pa
     if (K < 3) pr = pg = pb = pa = 1;
     double mindist = 2147483647.0;
     const int ca = c_alpha(c), cr = c_red(c), cg = c_green(c), cb = c_blue(c);
+    if (lists && lists->nearest && ca == 255 && k == 0) {
+        // exact candidate list of the colour's cell (nq_lists.inc), scanned in index order with the unchanged arithmetic
+        const CellList cl = load_cell_list(lists->nearest, lists->nearestCount, cell_of(c));
+        if (cl.n != NQ_LIST_FULLSCAN) {
+            for (int t = 0; t < cl.n; ++t) {
+                const int i = cl.at(t);
+                const int c2 = pal.argb[i];
+                double curdist = pa * sqr((double) (c_alpha(c2) - ca));
+                curdist += pr * sqr((double) (c_red(c2) - cr));
+                curdist += pg * sqr((double) (c_green(c2) - cg));
+                curdist += pb * sqr((double) (c_blue(c2) - cb));
+                if (curdist > mindist) continue;          // (the partial-sum gates of the reference only skip what this one skips)
+                mindist = curdist;
+                k = i;
+            }
+            return k;
+        }
+    }
     for (int i = k; i < K; ++i) {
         int c2 = pal.argb[i];
         double curdist = pa * sqr((double) (c_alpha(c2) - ca));
@@ -471,7 +489,7 @@ __device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pa
 }
 
 __device__ __forceinline__ int nearest_any(const DevParams& P, const PalView& pal, int c, const CellLists* lists = nullptr) {
-    return P.kind == 0 ? nearest_rgb(P, pal, c) : nearest_lab(P, pal, c, lists);
+    return P.kind == 0 ? nearest_rgb(P, pal, c, lists) : nearest_lab(P, pal, c, lists);
 }
 
 // ---- closest[] tuple ------------------------------------------------------------------------------
@@ -518,6 +536,32 @@ __device__ __forceinline__ void closest_step_lab(const DevParams& P, const PalVi
                                                  double wr, double wg, double wb, double ratio, int closest[4]) {
     const int c2 = pal.argb[k];
     const int dr = c_red(c2) - cr, dg = c_green(c2) - cg, db = c_blue(c2) - cb;
+    if (ratio < 0) {
+        // the ratio ladder of the reference can go negative (NQ/PnnLABQuantizer.java:259-264); the YUV terms then LOWER the sum
+        // and the gates decide: literal evaluation (:419-457)
+        double err = wr * sqr((double) dr);
+        if (err >= closest[3]) return;
+        err += wg * sqr((double) dg);
+        if (err >= closest[3]) return;
+        err += wb * sqr((double) db);
+        if (err >= closest[3]) return;
+        if (P.hasSemi) err += P.PA * sqr((double) (c_alpha(c2) - ca));
+        for (int i = 0; i < 3; ++i) {
+            err += ratio * sqr((double) (k_coeffs[i][0] * dr));
+            if (err >= closest[3]) break;
+            err += ratio * sqr((double) (k_coeffs[i][1] * dg));
+            if (err >= closest[3]) break;
+            err += ratio * sqr((double) (k_coeffs[i][2] * db));
+            if (err >= closest[3]) break;
+        }
+        if (err < closest[2]) {
+            closest[1] = closest[0]; closest[3] = closest[2];
+            closest[0] = k; closest[2] = j_d2i(err);
+        } else if (err < closest[3]) {
+            closest[1] = k; closest[3] = j_d2i(err);
+        }
+        return;
+    }
     // Every term is >= 0 and every gate of the reference (`if (err >= closest[3]) break`) only leaves early a candidate whose
     // final err would be >= closest[3] as well, i.e. one that neither branch below takes: the sum is evaluated straight through,
     // same operations in the same order, and compared once (no divergent exits between twelve short terms).

@@ -51,9 +51,12 @@ void launch_build_lists(const DevParams& P, const int* d_palette, double wA, dou
                         unsigned char* d_nearestCount, hipStream_t s) {
     hipLaunchKernelGGL(build_closest_lists_kernel, dim3(65536 / 256), dim3(256), (size_t) P.K * sizeof(int), s, P, d_palette,
                        wA, wR, wG, wB, d_closest, d_closestCount);
-    if (nearest)
+    if (nearest && P.kind == 1)
         hipLaunchKernelGGL(build_nearest_lists_kernel, dim3(65536 / 256), dim3(256), palette_smem_bytes(P.kind, P.K), s, P, d_palette,
                            P.hasAlpha ? 1 : 0, d_box, d_nearest, d_nearestCount);
+    else if (nearest)      // RGB: the nearestColorIndex weights are pa, pr, pg, pb themselves
+        hipLaunchKernelGGL(build_nearest_rgb_lists_kernel, dim3(65536 / 256), dim3(256), (size_t) P.K * sizeof(int), s, P, d_palette,
+                           P.K < 3 ? 1.0 : P.PA, P.K < 3 ? 1.0 : P.PR, P.K < 3 ? 1.0 : P.PG, P.K < 3 ? 1.0 : P.PB, d_nearest, d_nearestCount);
 }
 
 void launch_saliency(const DevParams& P, int salSubst, const int* d_pixels, int64_t N, float* d_out, hipStream_t s) {

@@ -75,6 +75,9 @@ PAL_CASES = [
     (1, 64, lambda: synth.with_alpha(synth.gradient_noise(96, 96, 23), 23)),
     (1, 16, lambda: synth.gradient_noise(96, 96, 24)),
     (1, 300, lambda: synth.uniform_rgb(96, 96, 25)),
+    # the ratio ladder goes NEGATIVE here (4 colours out of 400 bins, NQ/PnnLABQuantizer.java:259-264): no interval bound holds,
+    # the scans must fall back to the exact path (found by tools/fuzz_parity.py)
+    (1, 4, lambda: synth.few_colors(128, 148, 508842683, 402)),
 ]
 
 
@@ -445,3 +448,26 @@ def test_whole_convert_sequential_equals_oracle_convert(nq, oracle, kind, K, dit
     assert len(out.palette) == len(want_pal) and (out.palette != want_pal).sum() == 0
     assert (out.argb != want_argb).sum() == 0
     assert (out.index.astype(np.int32) != want_idx).sum() == 0
+
+
+def test_negative_ratio_is_handled_literally(nq, oracle):
+    """NQ/PnnLABQuantizer.java:259-264 can make `ratio` NEGATIVE (5 colours out of ~690 bins: .036 - .0072 e^1.632): the CIEDE2000
+    terms then lower the find_nn sums and the YUV terms lower the closest error, so neither the interval bounds, nor the candidate
+    lists, nor the gate-free closest evaluation apply -- palette, closest tuples and the dithered image must still equal the
+    oracle's (found by tools/fuzz_parity.py)."""
+    img = synth.few_colors(112, 96, 37, 700)
+    K, seed = 5, 4
+    oq, want_pal = _oracle_palette(oracle, 1, img, K)
+    assert oq.params.ratio < 0, oq.params.ratio
+    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=seed, tile=(16, 16))
+    pal = gq.pnnquan(K)
+    assert gq.params.ratio == oq.params.ratio
+    assert (pal != want_pal).sum() == 0
+    cols = img.reshape(-1)[:6000]
+    assert (gq.closestTuple(pal, cols) != oq.closest_tuple(want_pal, cols)).sum() == 0
+    assert (gq.nearestColorIndex(pal, cols) != oq.nearest_index(want_pal, cols)).sum() == 0
+    for dither in (True, False):
+        oq.set_seed(seed)
+        want_argb, want_idx = oq.dither(want_pal, dither, tile=(16, 16))
+        got_argb, got_idx = gq.dither(pal, dither)
+        assert (got_idx.astype(np.int32) != want_idx).sum() == 0 and (got_argb != want_argb).sum() == 0

@@ -1,0 +1,20 @@
+"""Throughput of nq_convert_batch_device for either kind: python tools/batch_rate.py <batch> <kind 0|1> [side]"""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np, torch
+import nquant.android_amd as nq
+from nquant.android_amd import synth
+B = int(sys.argv[1]); kind = int(sys.argv[2]); W = H = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+cls = nq.PnnLABQuantizer if kind else nq.PnnQuantizer
+qs, ins, outs = [], [], []
+for b in range(B):
+    q = cls(np.zeros((1, 1), np.int32), mode=1, seed=3 + b)
+    q.width, q.height = W, H
+    qs.append(q); ins.append(synth.gradient_noise_torch(W, H, 3 + b)); outs.append(torch.empty(W * H, dtype=torch.int32, device="cuda"))
+idx = [torch.empty(W * H, dtype=torch.int16, device="cuda") for _ in range(B)]
+for it in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pals = nq.convert_batch_device(qs, [t.data_ptr() for t in ins], 256, True, [t.data_ptr() for t in outs], [t.data_ptr() for t in idx])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("kind %d batch %d: %.2f s, %.1f Mpx/s, %.2f ms per image, maxbins %d, stages %s" % (kind, B, dt, B * W * H / dt / 1e6, dt / B * 1e3,
+          qs[0].params.maxbins, {k: round(v, 2) for k, v in qs[0].stage_ms().items()}), flush=True)
