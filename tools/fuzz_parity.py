@@ -11,7 +11,7 @@ from nquant.android_amd import synth
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"      # 160..360 pixels a side (up to ~60k bins), palette + scalars only
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-Ks = [3, 4, 5, 8, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256]
+Ks = [3, 4, 5, 6, 7, 8, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 1000]
 t_end = time.time() + budget
 n_cases = n_bad = 0
 while time.time() < t_end:
