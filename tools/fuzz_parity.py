@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle parity sweep (palette + scalars, tiled dither, lookups) over image kinds, sizes, K and flags.
-python tools/fuzz_parity.py [seconds] [seed] [big]  -- prints every mismatch and a summary; exit code 1 on any mismatch."""
+python tools/fuzz_parity.py [seconds] [seed] [big|seq]  -- prints every mismatch and a summary; exit code 1 on any mismatch."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,7 +9,8 @@ import nquant.android_amd as nq
 from nquant.android_amd import synth
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-BIG = len(sys.argv) > 3 and sys.argv[3] == "big"      # 160..360 pixels a side (up to ~60k bins), palette + scalars only
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+SEQ = len(sys.argv) > 3 and sys.argv[3] == "seq"      # whole convert() in REFERENCE_SEQUENTIAL mode against the oracle's convert()      # 160..360 pixels a side (up to ~60k bins), palette + scalars only
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 Ks = [3, 4, 5, 6, 7, 8, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 1000]
 t_end = time.time() + budget
@@ -17,6 +18,8 @@ n_cases = n_bad = 0
 while time.time() < t_end:
     kind = int(rng.integers(0, 2))
     w, h = (int(rng.integers(160, 360)), int(rng.integers(160, 360))) if BIG else (int(rng.integers(17, 150)), int(rng.integers(17, 150)))
+    if SEQ:
+        w, h = int(rng.integers(9, 90)), int(rng.integers(9, 90))
     seed = int(rng.integers(1, 1 << 30))
     gen = int(rng.integers(0, 5))
     if gen == 0: img = synth.uniform_rgb(w, h, seed)
@@ -30,6 +33,22 @@ while time.time() < t_end:
     rseed = int(rng.integers(0, 1 << 20))
     tag = "kind %d %dx%d gen %d seed %d K %d dither %d tile %d" % (kind, w, h, gen, seed, K, dither, tile[0])
     try:
+        if SEQ:
+            Ks2 = K if rng.random() < 0.9 else int(rng.integers(1, 3))
+            oq = oracle_lib.OracleQuantizer(kind, img, seed=rseed)
+            try:
+                want_argb, want_idx, want_pal = oq.convert(Ks2, dither)
+            except RuntimeError:
+                continue                                  # the Java code would throw (setAlphaComponent)
+            gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=nq.MODE_REFERENCE_SEQUENTIAL, seed=rseed)
+            out = gq.convert(Ks2, dither)
+            n_cases += 1
+            if len(out.palette) != len(want_pal) or (out.palette != want_pal).any() or (out.argb != want_argb).any() \
+                    or (out.index.astype(np.int32) != want_idx).any():
+                n_bad += 1; print("SEQ CONVERT MISMATCH:", tag, "K used", Ks2, flush=True)
+            if n_cases % 25 == 0:
+                print("... %d cases, %d mismatches" % (n_cases, n_bad), flush=True)
+            continue
         oq = oracle_lib.OracleQuantizer(kind, img, seed=rseed)
         oq.prescan(K)
         want_pal = oq.pnnquan(K)
