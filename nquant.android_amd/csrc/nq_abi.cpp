@@ -157,6 +157,8 @@ struct nq_handle {
     DevBuf<int> d_palette, d_in, d_out_argb, d_colors, d_tuple;
     DevBuf<unsigned short> d_out_index;
     DevBuf<short> d_bincache, d_short;
+    DevBuf<int> d_seqlog;             // REFERENCE_SEQUENTIAL + LAB + dither=false: colours getLab() saw during the pass (+ 1 counter)
+    DevBuf<unsigned char> d_seqseen;  // ... and the palette entries it touched
     DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..19] merge stats, [20..21] distinct-colour result
     DevBuf<int> live3;                // merge loop: two live lists + position index
     int use_lists = 1;
@@ -602,10 +604,8 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     }
     const bool post = !dither && K > 32;
     float blueWeight = 1.0f;
-    if (post && h->kind == NQ_KIND_LAB) {
-        if (sequential)
-            NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "REFERENCE_SEQUENTIAL + LAB + dither=false + K>32 needs pixelMap.size() after the gilbert "
-                    "pass (NQ/PnnLABQuantizer.java:512); not tracked on the GPU");
+    const bool seq_lab_post = post && h->kind == NQ_KIND_LAB && sequential;   // needs pixelMap.size() AFTER the gilbert pass
+    if (post && h->kind == NQ_KIND_LAB && !sequential) {
         if (p.distinctColors <= 0) {
             int64_t cnt = 0;
             int rcd = distinct_colors(h, d_argb, n, 0, &cnt, nullptr);
@@ -652,9 +652,41 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         d_sal = h->sc->saliency.p;
     }
     rec(h, 5);       // stage "palette_fill" ends here: it includes the candidate-list build and the saliency map
+    int log_cap = 0;
+    if (seq_lab_post) {
+        // every colour handed to nearestColorIndex on a cache miss (<= 3 lookups per pixel) + a flag per palette entry
+        if (3 * n + 16 > 2147483647LL) NQ_FAIL(h, NQ_ERR_INVALID, "image too large for the sequential pixelMap log");
+        log_cap = (int) (3 * n + 16);
+        NQ_HIP(h, h->d_seqlog.reserve((size_t) log_cap + 4));
+        NQ_HIP(h, h->d_seqseen.reserve((size_t) K));
+        NQ_HIP(h, hipMemsetAsync(h->d_seqlog.p + log_cap, 0, sizeof(int), h->stream));
+        NQ_HIP(h, hipMemsetAsync(h->d_seqseen.p, 0, (size_t) K, h->stream));
+    }
     launch_gilbert(P, G, T, lv, (const int*) d_argb, d_sal, h->d_palette.p, h->d_bincache.p, (long long) seed, sequential ? 1 : 0,
-                   h->d_scalars.p, d_out_index, post ? nullptr : (int*) d_out_argb, h->stream);
+                   h->d_scalars.p, d_out_index, post ? nullptr : (int*) d_out_argb,
+                   seq_lab_post ? h->d_seqlog.p : nullptr, seq_lab_post ? h->d_seqlog.p + log_cap : nullptr,
+                   seq_lab_post ? h->d_seqseen.p : nullptr, log_cap, h->stream);
     rec(h, 6);
+    if (seq_lab_post) {
+        // pixelMap.size() at NQ/PnnLABQuantizer.java:512 = |{image colours as the histogram saw them} U {colours looked up on a
+        // nearest-cache miss} U {palette entries those lookups touched}| (getLab memoises all three).  Debugging mode: on the host.
+        int count = 0;
+        NQ_HIP(h, hipMemcpyAsync(&count, h->d_seqlog.p + log_cap, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        NQ_HIP(h, hipStreamSynchronize(h->stream));
+        if (count > log_cap) NQ_FAIL(h, NQ_ERR_HIP, "sequential pixelMap log overflow (internal error)");
+        std::vector<int32_t> all((size_t) n + count);
+        std::vector<unsigned char> seen(K);
+        NQ_HIP(h, hipMemcpy(all.data(), d_argb, (size_t) n * sizeof(int), hipMemcpyDeviceToHost));
+        if (count) NQ_HIP(h, hipMemcpy(all.data() + n, h->d_seqlog.p, (size_t) count * sizeof(int), hipMemcpyDeviceToHost));
+        NQ_HIP(h, hipMemcpy(seen.data(), h->d_seqseen.p, (size_t) K, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i)
+            if ((((uint32_t) all[i]) >> 24) <= 0xF) all[i] = p.transparentColor;      // the histogram's substitution (:141-142)
+        for (int i = 0; i < K; ++i) if (seen[i]) all.push_back((int32_t) palette[i]);
+        std::sort(all.begin(), all.end());
+        const int64_t distinct = (int64_t) (std::unique(all.begin(), all.end()) - all.begin());
+        const double delta = sqr(K) / (double) distinct;
+        blueWeight = delta > 0.023 ? 1.0f : (float) (37.013 * delta + 0.906);
+    }
     if (post)
         launch_bluenoise(P, h->d_palette.p, lv, (const int*) d_argb, width, height, blueWeight, (long long) seed, sequential ? 1 : 0,
                          h->d_bincache.p, h->d_scalars.p, d_out_index, (int*) d_out_argb, h->stream);

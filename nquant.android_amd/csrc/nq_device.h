@@ -398,7 +398,10 @@ __device__ __forceinline__ int nearest_rgb(const DevParams& P, const PalView& pa
 }
 
 // LAB: NQ/PnnLABQuantizer.java:337-401
-__device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pal, int c, const CellLists* lists = nullptr) {
+// `seen` (REFERENCE_SEQUENTIAL only, else nullptr): byte per palette entry, set where the reference calls getLab(palette[i])
+// (NQ/PnnLABQuantizer.java:345-350: every entry that passes the alpha gate) -- those colours enter pixelMap
+__device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pal, int c, const CellLists* lists = nullptr,
+                                           unsigned char* seen = nullptr) {
     const int K = P.K;
     int k = 0;
     if (c_alpha(c) <= 0xF) c = P.transparentColor;
@@ -406,12 +409,14 @@ __device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pa
     double mindist = 2147483647.0;
     const Lab lab1 = RGB2LAB_fast(c, pal.gamma);
     const int ca = c_alpha(c);
+    if (seen && !P.hasSemi) for (int i = k; i < K; ++i) seen[i] = 1;     // without the alpha term every entry passes the gate
     if (K <= 4) {
         const int cr = c_red(c), cg = c_green(c), cb = c_blue(c);
         for (int i = k; i < K; ++i) {
             int c2 = pal.argb[i];
             double curdist = P.hasSemi ? sqr((double) (c_alpha(c2) - ca)) / g_tab.exp1_5 : 0;
             if (curdist > mindist) continue;
+            if (seen) seen[i] = 1;
             curdist = sqr((double) (c_red(c2) - cr)) + sqr((double) (c_green(c2) - cg)) + sqr((double) (c_blue(c2) - cb));
             if (P.hasSemi) curdist += sqr((double) (c_alpha(c2) - ca));
             if (curdist > mindist) continue;
@@ -422,6 +427,7 @@ __device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pa
         for (int i = k; i < K; ++i) {
             double curdist = P.hasSemi ? sqr((double) (c_alpha(pal.argb[i]) - ca)) / g_tab.exp1_5 : 0;
             if (curdist > mindist) continue;
+            if (seen) seen[i] = 1;
             curdist += sqr((double) (pal.L[i] - lab1.L));
             if (curdist > mindist) continue;
             curdist += sqr((double) (pal.A[i] - lab1.A));
@@ -488,8 +494,9 @@ __device__ __forceinline__ int nearest_lab(const DevParams& P, const PalView& pa
     return k;
 }
 
-__device__ __forceinline__ int nearest_any(const DevParams& P, const PalView& pal, int c, const CellLists* lists = nullptr) {
-    return P.kind == 0 ? nearest_rgb(P, pal, c, lists) : nearest_lab(P, pal, c, lists);
+__device__ __forceinline__ int nearest_any(const DevParams& P, const PalView& pal, int c, const CellLists* lists = nullptr,
+                                           unsigned char* seen = nullptr) {
+    return P.kind == 0 ? nearest_rgb(P, pal, c, lists) : nearest_lab(P, pal, c, lists, seen);
 }
 
 // ---- closest[] tuple ------------------------------------------------------------------------------
@@ -606,7 +613,13 @@ __device__ __forceinline__ void closest_tuple_lab(const DevParams& P, const PalV
 // ---- the Ditherable the quantizer hands to the ditherers ------------------------------------------
 // (RGB NQ/PnnQuantizer.java:377-391, LAB NQ/PnnLABQuantizer.java:476-490).  `binCache` (nullable) is the
 // reference's nearestMap when it is keyed by histogram bin (REFERENCE_SEQUENTIAL mode only; -1 = empty).
+// REFERENCE_SEQUENTIAL + LAB: what getLab() adds to the reference's pixelMap while the gilbert pass runs (its size feeds the
+// BlueNoise weight, NQ/PnnLABQuantizer.java:512): the colours handed to nearestColorIndex on a cache miss and the palette entries
+// it touches.  One lane runs the chain, so a plain counter is enough.
+struct SeqLog { int* colors; int* count; unsigned char* seen; int cap; };
+__device__ __forceinline__ void seqlog_add(const SeqLog* l, int c) { const int i = (*l->count)++; if (i < l->cap) l->colors[i] = c; }
 struct LookupCtx {
+    const SeqLog* slog = nullptr;
     const DevParams* P;
     PalView pal;
     short* binCache;       // [65536] or nullptr (cache-miss semantics)
@@ -617,15 +630,19 @@ struct LookupCtx {
 
 __device__ __forceinline__ int nearest_cached(LookupCtx& cx, int c) {
     const DevParams& P = *cx.P;
+    unsigned char* seen = nullptr;
     if (cx.binCache != nullptr && P.binKeyed) {
         const int offset = getColorIndex(c, P.hasSemi != 0, P.hasAlpha != 0);
         short got = cx.binCache[offset];
         if (got >= 0) return got;
-        int k = nearest_any(P, cx.pal, c, cx.lists);
+        if (cx.slog && P.kind == 1) { seqlog_add(cx.slog, c_alpha(c) <= 0xF ? P.transparentColor : c); seen = cx.slog->seen; }
+        int k = nearest_any(P, cx.pal, c, cx.lists, seen);
         cx.binCache[offset] = (short) k;
         return k;
     }
-    return nearest_any(P, cx.pal, c, cx.lists);    // a cache keyed by the full colour is transparent: nearest is pure in c
+    // a cache keyed by the full colour is transparent: nearest is pure in c (and a repeated colour is already in pixelMap)
+    if (cx.slog && P.kind == 1) { seqlog_add(cx.slog, c_alpha(c) <= 0xF ? P.transparentColor : c); seen = cx.slog->seen; }
+    return nearest_any(P, cx.pal, c, cx.lists, seen);
 }
 
 // RGB closestColorIndex: NQ/PnnQuantizer.java:313-375

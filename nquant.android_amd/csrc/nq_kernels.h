@@ -64,7 +64,9 @@ void launch_lookup_only(const DevParams& P, const int* d_palette, const ListsVie
 // GilbertCurve.dither over every tile; writes indices (always) and ARGB (when d_argb != nullptr)
 void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
                     const float* d_saliency, const int* d_palette, short* d_binCache, long long seed, int sequential,
-                    long long* d_rng_state, unsigned short* d_index, int* d_argb, hipStream_t s);
+                    long long* d_rng_state, unsigned short* d_index, int* d_argb,
+                    // REFERENCE_SEQUENTIAL + LAB only (else null): log of the colours / palette entries getLab() sees during the pass
+                    int* d_log, int* d_log_count, unsigned char* d_seen, int log_cap, hipStream_t s);
 // BlueNoise.dither post-pass (NQ/BlueNoise.java:207-222); in-place on d_index, writes d_argb
 void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,
                       float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,

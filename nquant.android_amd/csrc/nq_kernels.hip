@@ -80,7 +80,7 @@ void launch_lookup_only(const DevParams& P, const int* d_palette, const ListsVie
 template <bool SORTED, int DM>
 static void launch_gilbert_t(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const CellLists& L, const int* d_pixels,
                              const float* d_saliency, const int* d_palette, short* d_binCache, long long seed, int sequential,
-                             long long* d_rng_state, unsigned short* d_index, int* d_argb, hipStream_t s) {
+                             long long* d_rng_state, unsigned short* d_index, int* d_argb, const SeqLog& slog, hipStream_t s) {
     const int ntiles = T.tiles_x * T.tiles_y;
     const int block = 64;
     const int grid = (ntiles + block - 1) / block;
@@ -89,24 +89,26 @@ static void launch_gilbert_t(const DevParams& P, const GilbertConsts& G, const T
     const bool stage = P.K <= 256 && tilepx <= 256 && !sequential;
     if (stage)
         hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, true>), dim3(grid), dim3(block), base + (size_t) 64 * tilepx, s, P, G, T, L, d_pixels,
-                           d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb);
+                           d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog);
     else
         hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, false>), dim3(grid), dim3(block), base, s, P, G, T, L, d_pixels,
-                           d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb);
+                           d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog);
 }
 
 void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
                     const float* d_saliency, const int* d_palette, short* d_binCache, long long seed, int sequential,
-                    long long* d_rng_state, unsigned short* d_index, int* d_argb, hipStream_t s) {
+                    long long* d_rng_state, unsigned short* d_index, int* d_argb, int* d_log, int* d_log_count, unsigned char* d_seen,
+                    int log_cap, hipStream_t s) {
     const CellLists L = to_lists(lv);
+    SeqLog slog; slog.colors = d_log; slog.count = d_log_count; slog.seen = d_seen; slog.cap = log_cap;
     if (G.sortedByYDiff)
-        launch_gilbert_t<true, 1>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, s);
+        launch_gilbert_t<true, 1>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, s);
     else if (G.DITHER_MAX == 25)
-        launch_gilbert_t<false, 25>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, s);
+        launch_gilbert_t<false, 25>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, s);
     else if (G.DITHER_MAX == 16)
-        launch_gilbert_t<false, 16>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, s);
+        launch_gilbert_t<false, 16>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, s);
     else
-        launch_gilbert_t<false, 9>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, s);
+        launch_gilbert_t<false, 9>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, s);
 }
 
 void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,

@@ -433,7 +433,9 @@ def test_convert_batch_host_equals_device_batch(nq):
 
 
 @pytest.mark.parametrize("kind,K,dither,alpha", [(0, 2, True, False), (0, 2, False, True), (1, 2, True, True), (1, 2, False, False),
-                                                 (1, 1, True, False), (0, 16, False, False), (1, 8, True, True), (0, 300, True, False)])
+                                                 (1, 1, True, False), (0, 16, False, False), (1, 8, True, True), (0, 300, True, False),
+                                                 # LAB, no dither, K > 32: the BlueNoise weight needs pixelMap.size() after the gilbert pass (:512)
+                                                 (1, 256, False, False), (1, 64, False, True), (1, 100, False, False)])
 def test_whole_convert_sequential_equals_oracle_convert(nq, oracle, kind, K, dither, alpha):
     """convert(n, dither) end to end in REFERENCE_SEQUENTIAL mode == the oracle's convert(), including nMaxColors <= 2 (fixed
     two-colour palette, alpha-0 pixels read as the transparent colour, NQ/PnnQuantizer.java:424,441-452) and RGB K > 256."""
