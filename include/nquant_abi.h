@@ -175,6 +175,16 @@ int nq_band_histogram_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pix
 int nq_palette_from_histograms_device(nq_handle* h, const double* d_hists, int n_bands, int nMaxColors,
                                       uint32_t* out_palette, int32_t* out_K);
 
+/* few-colours early return of the LAB class (NQ/PnnLABQuantizer.java:193-206) in the split pipeline: when the gathered histograms
+ * hold <= nMaxColors occupied bins, every rank lists the distinct colours of its band as the histogram sees them (alpha <= 15 ->
+ * transparent colour; needs nq_set_scan first) in first-occurrence order -- *out_count = how many there are, out_colors filled
+ * when *out_count <= cap -- the caller concatenates the lists in band order, drops repeats, and hands the image-wide list to
+ * every rank with nq_set_distinct (count < 0 = "more than nMaxColors": no early return).  nq_palette_from_histograms_device then takes the
+ * same early return as a single GPU would. */
+int nq_band_distinct_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, int cap, int64_t* out_count,
+                            uint32_t* out_colors);
+int nq_set_distinct(nq_handle* h, int64_t count, const uint32_t* colors);
+
 /* Wall-clock of the stages of the last nq_convert*_ call on this handle, milliseconds, measured with HIP
  * events on the handle's stream: {prescan, histogram, nn_init, merge, palette_fill, dither, bluenoise, total}. */
 #define NQ_N_STAGES 8

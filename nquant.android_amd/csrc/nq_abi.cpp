@@ -170,6 +170,8 @@ struct nq_handle {
     DevBuf<unsigned short> ring_index[3];
     hipStream_t copy_stream = nullptr;
     long long merge_stats[16] = {0};
+    bool ext_distinct_valid = false, ext_distinct_many = false;  // nq_set_distinct: image-wide distinct colours (first-occurrence order) of the split pipeline
+    std::vector<int32_t> ext_distinct;
     DevBuf<int> d_ints;               // [0] maxbins, [1] status, [8..71] occupied slots per 1024-slot slice
     DevBuf<int> heap;
     DevBuf<float> binf;               // f[4], cnt, err : 6 x 65536
@@ -403,14 +405,19 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
         }
         if (maxbins <= nMaxColors) {
             // pixelMap.size() <= nMaxColors is only possible here (every occupied bin holds >= 1 distinct colour)
-            if (!d_argb)
-                NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "<= nMaxColors occupied bins in the multi-band path: the pixelMap.size() <= nMaxColors "
-                        "early return (NQ/PnnLABQuantizer.java:193-206) needs the whole image on one GPU");
             int64_t cnt = 0;
             std::vector<int32_t> inserted;
-            int rcd = distinct_colors(h, d_argb, n_pixels, nMaxColors, &cnt, &inserted);
-            if (rcd) return rcd;
-            p.distinctColors = cnt;
+            if (d_argb) {
+                int rcd = distinct_colors(h, d_argb, n_pixels, nMaxColors, &cnt, &inserted);
+                if (rcd) return rcd;
+            } else if (h->ext_distinct_valid) {                 // split pipeline: the caller merged the bands' lists
+                inserted = h->ext_distinct;
+                cnt = h->ext_distinct_many ? (int64_t) nMaxColors + 1 : (int64_t) inserted.size();
+            } else
+                NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "<= nMaxColors occupied bins in the multi-band path: exchange the bands' distinct colours "
+                        "(nq_band_distinct_device / nq_set_distinct) before nq_palette_from_histograms_device "
+                        "(NQ/PnnLABQuantizer.java:193-206)");
+            p.distinctColors = (!d_argb && h->ext_distinct_many) ? 0 : cnt;     // (0 = not known: "more than nMaxColors")
             if (cnt <= nMaxColors) {
                 // NQ/PnnLABQuantizer.java:193-206: palette = pixelMap.keySet() in HashMap order, a transparent colour swapped to slot 0
                 std::vector<int32_t> keys = java_hashmap_keyset(inserted);
@@ -1068,6 +1075,30 @@ int nq_band_scan_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, 
 int nq_set_scan(nq_handle* h, int nMaxColors, int64_t transparent_index, uint32_t transparent_color, int64_t semi_count) {
     if (!h) return NQ_ERR_INVALID;
     apply_scan(h, nMaxColors, transparent_index, transparent_color, semi_count);
+    return NQ_OK;
+}
+
+int nq_band_distinct_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, int cap, int64_t* out_count, uint32_t* out_colors) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!d_argb || n_pixels <= 0 || cap < 1 || !out_count || !out_colors) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    std::vector<int32_t> cols;
+    rc = distinct_colors(h, d_argb, n_pixels, cap, out_count, &cols);
+    if (rc) return rc;
+    if (*out_count <= cap) std::memcpy(out_colors, cols.data(), cols.size() * sizeof(int32_t));
+    return NQ_OK;
+}
+
+int nq_set_distinct(nq_handle* h, int64_t count, const uint32_t* colors) {
+    if (!h) return NQ_ERR_INVALID;
+    h->ext_distinct_valid = true;
+    h->ext_distinct_many = count < 0;
+    h->ext_distinct.clear();
+    if (count > 0) {
+        if (!colors) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+        h->ext_distinct.assign((const int32_t*) colors, (const int32_t*) colors + count);
+    }
     return NQ_OK;
 }
 

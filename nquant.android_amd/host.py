@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "nq_abi_version", "nq_create", "nq_destroy", "nq_last_error", "nq_set_stream", "nq_set_tile", "nq_set_option", "nq_get_list_counts", "nq_get_params",
     "nq_set_params", "nq_convert", "nq_convert_device", "nq_convert_batch_device", "nq_convert_batch", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
-    "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_get_stage_ms", "nq_get_merge_stats",
+    "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_band_distinct_device", "nq_set_distinct", "nq_get_stage_ms", "nq_get_merge_stats",
 ]
 
 
@@ -111,6 +111,8 @@ def load_library():
     L.nq_set_scan.argtypes = [vp, i32, i64, C.c_uint32, i64]
     L.nq_band_histogram_device.argtypes = [vp, vp, i64, vp]
     L.nq_palette_from_histograms_device.argtypes = [vp, vp, i32, i32, vp, C.POINTER(C.c_int32)]
+    L.nq_band_distinct_device.argtypes = [vp, vp, i64, i32, vp, vp]
+    L.nq_set_distinct.argtypes = [vp, i64, vp]
     L.nq_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nq_get_merge_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     _LIB = L

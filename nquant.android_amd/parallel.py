@@ -59,6 +59,37 @@ def _gather_small(t, group=None):
     return torch.stack(parts).cpu()
 
 
+def band_distinct(q, d_band, n, cap):
+    """Distinct colours of this band (first-occurrence order) or None when there are more than `cap`."""
+    import ctypes as C
+    cnt = C.c_int64(0)
+    cols = np.zeros(cap, np.int32)
+    q._check(q._L.nq_band_distinct_device(q._h, C.c_void_p(d_band.data_ptr()), n, cap, C.byref(cnt), cols.ctypes.data))
+    return None if cnt.value > cap else [int(c) for c in cols[:cnt.value]]
+
+
+def merge_distinct(mine, cap, group=None):
+    """mine: this band's distinct colours in first-occurrence order, or None (= more than cap).  Returns the image-wide list in
+    first-occurrence order (bands in rank order, repeats dropped), or None when it is longer than cap.  Fixed-size exchange:
+    int64[cap + 1] = {count or -1, colours...}."""
+    t = torch.full((cap + 1,), -1, dtype=torch.int64)
+    if mine is not None and len(mine) <= cap:
+        t[0] = len(mine)
+        if mine:
+            t[1:1 + len(mine)] = torch.tensor(mine, dtype=torch.int64)
+    allv = _gather_small(t, group)
+    out, seen = [], set()
+    for r in range(allv.shape[0]):
+        k = int(allv[r, 0])
+        if k < 0:
+            return None
+        for c in allv[r, 1:1 + k].tolist():
+            if c not in seen:
+                seen.add(c)
+                out.append(int(c))
+    return out if len(out) <= cap else None
+
+
 def max_over_ranks(seconds, device="cpu", group=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -78,6 +109,12 @@ def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_ar
     hist = torch.empty(HIST_BINS * HIST_STRIDE, dtype=torch.float64, device=d_band.device)
     q._check(L.nq_band_histogram_device(q._h, C.c_void_p(d_band.data_ptr()), n, C.c_void_p(hist.data_ptr())))
     hists = gather_histograms(hist, group)
+    if q.KIND == 1 and int((hists.view(hists.shape[0], HIST_BINS, HIST_STRIDE)[:, :, 0].sum(0) > 0).sum()) <= nMaxColors:
+        # NQ/PnnLABQuantizer.java:193-206: with so few occupied bins the image may hold <= nMaxColors distinct colours, and the
+        # reference then returns them as they are -- every rank takes this branch together (the gathered histograms are identical)
+        merged = merge_distinct(band_distinct(q, d_band, n, nMaxColors), nMaxColors, group)
+        cols = np.asarray(merged if merged is not None else [], np.int32)
+        q._check(L.nq_set_distinct(q._h, len(cols) if merged is not None else -1, cols.ctypes.data))
     pal = np.zeros(max(nMaxColors, 2), np.int32)
     K = C.c_int32(0)
     q._check(L.nq_palette_from_histograms_device(q._h, C.c_void_p(hists.data_ptr()), hists.shape[0], nMaxColors,

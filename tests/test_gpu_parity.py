@@ -473,3 +473,63 @@ def test_negative_ratio_is_handled_literally(nq, oracle):
         want_argb, want_idx = oq.dither(want_pal, dither, tile=(16, 16))
         got_argb, got_idx = gq.dither(pal, dither)
         assert (got_idx.astype(np.int32) != want_idx).sum() == 0 and (got_argb != want_argb).sum() == 0
+
+
+def test_banded_pipeline_few_colours_early_return(nq, oracle):
+    """Split pipeline, image with <= nMaxColors distinct colours: the bands' distinct colours are exchanged
+    (nq_band_distinct_device -> parallel.merge_distinct -> nq_set_distinct) and the palette is the reference's early return
+    (NQ/PnnLABQuantizer.java:193-206) -- one rank through convert_banded, and two bands driven by hand on one GPU."""
+    import ctypes as C
+    import os
+    import torch
+    import torch.distributed as dist
+    from nquant.android_amd import parallel
+    img = synth.with_alpha(synth.few_colors(64, 64, 72, 60), 72)
+    H, W = img.shape
+    K = 256
+    oq, want = _oracle_palette(oracle, 1, img, K)
+    assert len(want) <= K and oq.params.maxbins <= K        # the early-return case
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29519")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        d_band = torch.from_numpy(img.reshape(-1)).cuda()
+        d_out = torch.empty(W * H, dtype=torch.int32, device="cuda")
+        q = nq.PnnLABQuantizer(img, mode=TILED, seed=3, tile=(16, 16))
+        got = parallel.convert_banded(q, d_band, W, H, 0, K, True, d_out)
+        torch.cuda.synchronize()
+        assert len(got) == len(want) and (got == want).all()
+    finally:
+        dist.destroy_process_group()
+    # two bands by hand: per-band lists concatenated in band order, repeats dropped == the whole image's first-occurrence order
+    q = nq.PnnLABQuantizer(img, mode=TILED, seed=3)
+    L = q._L
+    halves = [(0, H // 2), (H // 2, H)]
+    d_bands = [torch.from_numpy(np.ascontiguousarray(img[a:b]).reshape(-1)).cuda() for a, b in halves]
+    scans = []
+    for (a, b), d in zip(halves, d_bands):
+        s3 = torch.empty(3, dtype=torch.int64, device="cuda")
+        q._check(L.nq_band_scan_device(q._h, C.c_void_p(d.data_ptr()), d.numel(), a * W, K, C.c_void_p(s3.data_ptr())))
+        scans.append(s3.cpu())
+    allv = torch.stack(scans)
+    win = int(torch.argmax(allv[:, 0]))
+    q._check(L.nq_set_scan(q._h, K, int(allv[win, 0]), C.c_uint32(int(allv[win, 1]) & 0xFFFFFFFF), int(allv[:, 2].sum())))
+    hists, lists = [], []
+    for d in d_bands:
+        hst = torch.empty(65536 * 5, dtype=torch.float64, device="cuda")
+        q._check(L.nq_band_histogram_device(q._h, C.c_void_p(d.data_ptr()), d.numel(), C.c_void_p(hst.data_ptr())))
+        hists.append(hst)
+        lists.append(parallel.band_distinct(q, d, d.numel(), K))
+    merged, seen = [], set()
+    for lst in lists:
+        for c in lst:
+            if c not in seen:
+                seen.add(c); merged.append(c)
+    cols = np.asarray(merged, np.int32)
+    q._check(L.nq_set_distinct(q._h, len(cols), cols.ctypes.data))
+    hs = torch.stack(hists)
+    pal = np.zeros(K, np.int32)
+    Kout = C.c_int32(0)
+    q._check(L.nq_palette_from_histograms_device(q._h, C.c_void_p(hs.data_ptr()), 2, K, pal.ctypes.data, C.byref(Kout)))
+    assert Kout.value == len(want) and (pal[:Kout.value] == want).all()

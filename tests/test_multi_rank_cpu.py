@@ -64,6 +64,18 @@ def _worker(rank, world, port, tmp):
     assert (hists[rank].numpy() == hist.numpy()).all()  # band order == rank order
     t = parallel.max_over_ranks(1.0 + rank)
     assert t == float(world)
+    # distinct-colour exchange of the few-colours early return: band lists in rank order, repeats dropped, None = "too many"
+    few = synth.few_colors(W, H, 11, 9)
+    def first_seen(a):
+        out, seen = [], set()
+        for c in a.reshape(-1).tolist():
+            if c not in seen:
+                seen.add(c); out.append(c)
+        return out
+    mine = first_seen(few[y0:y1])
+    assert parallel.merge_distinct(mine, 16) == first_seen(few)
+    assert parallel.merge_distinct(mine, 4) is None                        # more than cap colours overall
+    assert parallel.merge_distinct(None if rank == 1 else mine, 16) is None  # one band reported "too many"
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
