@@ -105,7 +105,13 @@ def main():
     import threading
     import nquant.android_amd as nq
     from nquant.android_amd import synth
-    nq.build_library()
+    # the library ships prebuilt with the repo snapshot; should a rebuild be needed, exactly one rank does it
+    if dist is None:
+        nq.build_library()
+    else:
+        if rank == 0:
+            nq.build_library()
+        dist.barrier()
 
     W = H = args.size
     npx = W * H
