@@ -210,12 +210,15 @@ def main():
             stages[k] = stages.get(k, 0.0) + v
     stages = {k: v / max(nrec, 1) for k, v in stages.items()}
     pals = groups[0]["pals"]
-    # sanity of the timed work itself: every output pixel is its palette entry
-    s0 = slots[0]
-    palt = torch.from_numpy(pals[0]).cuda()
-    ok = bool((palt[(s0["idx"].to(torch.int64) & 0xFFFF)] == s0["out"]).all())
-    if not ok:
-        raise SystemExit("bench: output pixels do not match palette[index]")
+    # sanity of the timed work itself: every output pixel is its palette entry, palettes are full and differ between images
+    g0 = groups[0]
+    for k in sorted({0, len(g0["slots"]) // 2, len(g0["slots"]) - 1}):
+        sk = g0["slots"][k]
+        palt = torch.from_numpy(pals[k]).cuda()
+        if len(pals[k]) != 256 or not bool((palt[(sk["idx"].to(torch.int64) & 0xFFFF)] == sk["out"]).all()):
+            raise SystemExit("bench: output pixels of image %d do not match palette[index]" % k)
+    if len(g0["slots"]) > 1 and bool((pals[0] == pals[-1]).all()):
+        raise SystemExit("bench: distinct images produced identical palettes")
 
     if rank == 0:
         p = q0.params
