@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle parity sweep (palette + scalars, tiled dither, lookups) over image kinds, sizes, K and flags.
-python tools/fuzz_parity.py [seconds] [seed] [big|seq]  -- prints every mismatch and a summary; exit code 1 on any mismatch."""
+python tests/fuzz_parity.py [seconds] [seed] [big|seq]  -- prints every mismatch and a summary; exit code 1 on any mismatch."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,3 +1,4 @@
+"""Palette parity (GPU vs oracle) on three medium images with the merge-loop counters: python tests/pnn_check.py  (needs a GPU)"""
 import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import numpy as np, oracle_lib as O, nquant.android_amd as nq
 from nquant.android_amd import synth

@@ -1,4 +1,4 @@
-"""Re-runs one fuzz case: python tools/repro_case.py kind w h gen seed K   (prints both palettes and the scalars)"""
+"""Re-runs one fuzz case: python tests/repro_case.py kind w h gen seed K   (prints both palettes and the scalars)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

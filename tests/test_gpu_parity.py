@@ -76,7 +76,7 @@ PAL_CASES = [
     (1, 16, lambda: synth.gradient_noise(96, 96, 24)),
     (1, 300, lambda: synth.uniform_rgb(96, 96, 25)),
     # the ratio ladder goes NEGATIVE here (4 colours out of 400 bins, NQ/PnnLABQuantizer.java:259-264): no interval bound holds,
-    # the scans must fall back to the exact path (found by tools/fuzz_parity.py)
+    # the scans must fall back to the exact path (found by tests/fuzz_parity.py)
     (1, 4, lambda: synth.few_colors(128, 148, 508842683, 402)),
 ]
 
@@ -456,7 +456,7 @@ def test_negative_ratio_is_handled_literally(nq, oracle):
     """NQ/PnnLABQuantizer.java:259-264 can make `ratio` NEGATIVE (5 colours out of ~690 bins: .036 - .0072 e^1.632): the CIEDE2000
     terms then lower the find_nn sums and the YUV terms lower the closest error, so neither the interval bounds, nor the candidate
     lists, nor the gate-free closest evaluation apply -- palette, closest tuples and the dithered image must still equal the
-    oracle's (found by tools/fuzz_parity.py)."""
+    oracle's (found by tests/fuzz_parity.py)."""
     img = synth.few_colors(112, 96, 37, 700)
     K, seed = 5, 4
     oq, want_pal = _oracle_palette(oracle, 1, img, K)
