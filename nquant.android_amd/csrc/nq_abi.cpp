@@ -169,6 +169,7 @@ struct nq_handle {
     DevBuf<int> ring_argb[3];         // nq_convert_batch: device output ring (results leave for the host while the next image runs)
     DevBuf<unsigned short> ring_index[3];
     hipStream_t copy_stream = nullptr;
+    hipStream_t lane_stream = nullptr;  // second lane of the batch entry points
     long long merge_stats[16] = {0};
     bool ext_distinct_valid = false, ext_distinct_many = false;  // nq_set_distinct: image-wide distinct colours (first-occurrence order) of the split pipeline
     std::vector<int32_t> ext_distinct;
@@ -184,6 +185,7 @@ struct nq_handle {
         for (auto& kv : paths) (void) hipFree(kv.second);
         for (auto& e : ev) if (e) (void) hipEventDestroy(e);
         if (copy_stream) (void) hipStreamDestroy(copy_stream);
+        if (lane_stream) (void) hipStreamDestroy(lane_stream);
     }
 };
 
@@ -870,7 +872,9 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
         if (hs[i]->device != h0->device) NQ_FAIL(h0, NQ_ERR_INVALID, "handles of a batch must share one device");
         for (int j = 0; j < i; ++j) if (hs[j] == hs[i]) NQ_FAIL(h0, NQ_ERR_INVALID, "a handle appears twice in the batch");
     }
-    // the whole batch runs on the first handle's stream and shares its per-pixel scratch (stages of different images never overlap)
+    // The per-image stages run on TWO lanes (even images: the first handle's stream and per-pixel scratch; odd images: a second
+    // stream and the second handle's scratch): while the host waits for a read-back of one image, the queued kernels of the
+    // other lane keep the GPU busy (stages before the merge loop: three read-backs per image).  The merge launch joins the lanes.
     struct Restore {
         nq_handle* const* hs; int n; std::vector<hipStream_t> streams;
         ~Restore() { for (int i = 0; i < n; ++i) { hs[i]->stream = streams[i]; hs[i]->sc = &hs[i]->own; } }
@@ -881,8 +885,11 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
         int rc = use_device(hs[i]);            // tables / events on the handle's own stream, before it is redirected
         if (rc) return fail_from(hs[i], rc);
         if (i) NQ_HIP(h0, hipStreamSynchronize(hs[i]->stream));
-        hs[i]->stream = h0->stream; hs[i]->sc = &h0->own;
     }
+    if (n > 1 && !h0->lane_stream) NQ_HIP(h0, hipStreamCreateWithFlags(&h0->lane_stream, hipStreamNonBlocking));
+    hipStream_t lane_s[2] = {h0->stream, n > 1 ? h0->lane_stream : h0->stream};
+    Scratch* lane_sc[2] = {&h0->own, n > 1 ? &hs[1]->own : &h0->own};
+    for (int i = 0; i < n; ++i) { hs[i]->stream = lane_s[i & 1]; hs[i]->sc = lane_sc[i & 1]; }
     std::vector<PaletteJob> jobs(n);
     std::vector<const PaletteJob*> jp(n);
     for (int i = 0; i < n; ++i) {
@@ -891,8 +898,11 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
         if (rc) return fail_from(hs[i], rc);
         jp[i] = &jobs[i];
     }
+    if (n > 1) NQ_HIP(h0, hipStreamSynchronize(lane_s[1]));          // every prepare has been issued: join before the merge launch
     int rc = merge_launch(h0, jp.data(), n);
     if (rc) return rc;
+    // behind the merge launch everything runs on lane 0 again: two dither kernels side by side would only slow each other down
+    for (int i = 0; i < n; ++i) { hs[i]->stream = lane_s[0]; hs[i]->sc = lane_sc[0]; }
     for (int i = 0; i < n; ++i) if (jobs[i].merge) rec(hs[i], 4);
     for (int i = 0; i < n; ++i) {
         uint32_t* pal = out_palettes + (size_t) i * palette_stride;
@@ -904,7 +914,7 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
                            d_out_index ? d_out_index[i] : nullptr);
         if (rc) return fail_from(hs[i], rc);
     }
-    NQ_HIP(h0, hipStreamSynchronize(h0->stream));
+    NQ_HIP(h0, hipStreamSynchronize(lane_s[0]));
     for (int i = 0; i < n; ++i) finish_timing(hs[i]);
     return NQ_OK;
 }
