@@ -86,7 +86,13 @@ int nq_set_tile(nq_handle* h, int tile_w, int tile_h);
 /* Tuning switches that never change results.  NQ_OPT_CELL_LISTS (default 1): scan only the per-colour-cell candidate
  * lists in nearest/closestColorIndex (exact, csrc/nq_lists.inc); 0 = scan the whole palette like the reference. */
 #define NQ_OPT_CELL_LISTS 1
+/* NQ_OPT_FAST_DITHER (default 1): run the specialised dither kernel (csrc/nq_dither_fast.inc) where the configuration allows
+ * it (LAB, 32 < K <= 256, no semi-transparency, DITHER_MAX 25, PARALLEL_TILED); 0 = the generic kernel everywhere.  Same results. */
+#define NQ_OPT_FAST_DITHER 2
 int nq_set_option(nq_handle* h, int option, int value);
+/* Diagnostics of the last dither pass: out_fast = 1 if the specialised kernel ran; out_failed_tiles = tiles it handed back to
+ * the generic kernel (synchronises the handle's stream). */
+int nq_get_dither_path(nq_handle* h, int32_t* out_fast, int32_t* out_failed_tiles);
 /* Diagnostics: length of every cell's candidate list of the last dither/lookup call (255 = full scan), 65536 bytes each. */
 int nq_get_list_counts(nq_handle* h, uint8_t* closest_counts, uint8_t* nearest_counts);
 int nq_get_params(const nq_handle* h, nq_params* out);

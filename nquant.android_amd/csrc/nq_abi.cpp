@@ -162,6 +162,10 @@ struct nq_handle {
     DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..19] merge stats, [20..21] distinct-colour result
     DevBuf<int> live3;                // merge loop: two live lists + position index
     int use_lists = 1;
+    int use_fast_dither = 1;          // NQ_OPT_FAST_DITHER: the specialised dither kernel where the configuration allows it
+    int last_dither_fast = 0;         // diagnostics: 1 if the last dither pass ran gilbert_fast_kernel
+    int last_dither_failed_tiles = 0; // ... and how many tiles it handed back to the generic kernel (read lazily)
+    DevBuf<int> d_failed;             // {count, tile indices...} of those tiles
     DevBuf<float> scan_f;             // merge loop: position-indexed scan arrays (two generations)
     DevBuf<int> scan_i;
     DevBuf<float> scan_box;           // merge loop: bounding boxes of the 64-position blocks (1024 x 8 floats)
@@ -605,7 +609,10 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     const bool sequential = mode == NQ_MODE_REFERENCE_SEQUENTIAL;
 
     // dither(): RGB NQ/PnnQuantizer.java:393-407, LAB NQ/PnnLABQuantizer.java:493-522
-    if (p.hasSemiTransparency) p.weight *= -1;
+    // The reference negates the field once per convert() (dither() runs once per object); here dither may be called repeatedly on
+    // one handle, so the negation holds for this call only and the handle keeps the value pnnquan left.
+    struct WeightGuard { double& w; double saved; ~WeightGuard() { w = saved; } } weight_guard{p.weight, p.weight};
+    if (p.hasSemiTransparency) p.weight = -std::fabs(p.weight);
     bool hasSal = false, salSubst = false;
     if (h->kind == NQ_KIND_LAB) {
         if (p.nMaxColors > 2 && p.nMaxColors < 128) { hasSal = true; salSubst = true; }       // pnnquan :135,:155-156
@@ -671,10 +678,20 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         NQ_HIP(h, hipMemsetAsync(h->d_seqlog.p + log_cap, 0, sizeof(int), h->stream));
         NQ_HIP(h, hipMemsetAsync(h->d_seqseen.p, 0, (size_t) K, h->stream));
     }
+    const int* d_tile_list = nullptr;
+    h->last_dither_fast = 0;
+    if (!sequential && h->use_fast_dither && gilbert_fast_eligible(P, G, T, lv)) {
+        // production path (nq_dither_fast.inc); the tiles it cannot finish come back as a list for the generic kernel below
+        NQ_HIP(h, h->d_failed.reserve((size_t) T.tiles_x * T.tiles_y + 1));
+        launch_gilbert_fast(P, G, T, lv, (const int*) d_argb, d_sal, h->d_palette.p, (long long) seed, d_out_index,
+                            post ? nullptr : (int*) d_out_argb, h->d_failed.p, h->stream);
+        d_tile_list = h->d_failed.p;
+        h->last_dither_fast = 1;
+    }
     launch_gilbert(P, G, T, lv, (const int*) d_argb, d_sal, h->d_palette.p, h->d_bincache.p, (long long) seed, sequential ? 1 : 0,
                    h->d_scalars.p, d_out_index, post ? nullptr : (int*) d_out_argb,
                    seq_lab_post ? h->d_seqlog.p : nullptr, seq_lab_post ? h->d_seqlog.p + log_cap : nullptr,
-                   seq_lab_post ? h->d_seqseen.p : nullptr, log_cap, h->stream);
+                   seq_lab_post ? h->d_seqseen.p : nullptr, log_cap, d_tile_list, h->stream);
     rec(h, 6);
     if (seq_lab_post) {
         // pixelMap.size() at NQ/PnnLABQuantizer.java:512 = |{image colours as the histogram saw them} U {colours looked up on a
@@ -775,7 +792,22 @@ int nq_get_list_counts(nq_handle* h, uint8_t* closest_counts, uint8_t* nearest_c
 int nq_set_option(nq_handle* h, int option, int value) {
     if (!h) return NQ_ERR_INVALID;
     if (option == NQ_OPT_CELL_LISTS) { h->use_lists = value != 0; return NQ_OK; }
+    if (option == NQ_OPT_FAST_DITHER) { h->use_fast_dither = value != 0; return NQ_OK; }
     NQ_FAIL(h, NQ_ERR_INVALID, "unknown option %d", option);
+}
+int nq_get_dither_path(nq_handle* h, int32_t* out_fast, int32_t* out_failed_tiles) {
+    if (!h) return NQ_ERR_INVALID;
+    if (out_fast) *out_fast = h->last_dither_fast;
+    if (out_failed_tiles) {
+        *out_failed_tiles = 0;
+        if (h->last_dither_fast && h->d_failed.p) {
+            NQ_HIP(h, hipStreamSynchronize(h->stream));
+            int cnt = 0;
+            NQ_HIP(h, hipMemcpy(&cnt, h->d_failed.p, sizeof(int), hipMemcpyDeviceToHost));
+            *out_failed_tiles = cnt;
+        }
+    }
+    return NQ_OK;
 }
 int nq_get_params(const nq_handle* h, nq_params* out) {
     if (!h || !out) return NQ_ERR_INVALID;

@@ -23,7 +23,9 @@ ABI_SYMBOLS = [
     "nq_set_params", "nq_convert", "nq_convert_device", "nq_convert_batch_device", "nq_convert_batch", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
     "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_band_distinct_device", "nq_set_distinct", "nq_get_stage_ms", "nq_get_merge_stats",
+    "nq_get_dither_path",
 ]
+OPT_CELL_LISTS, OPT_FAST_DITHER = 1, 2
 
 
 def abi_symbols():
@@ -115,6 +117,7 @@ def load_library():
     L.nq_set_distinct.argtypes = [vp, i64, vp]
     L.nq_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nq_get_merge_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.nq_get_dither_path.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     _LIB = L
     return L
 
@@ -190,6 +193,12 @@ class PnnQuantizer:
 
     def set_option(self, option, value):
         self._check(self._L.nq_set_option(self._h, int(option), int(value)))
+
+    def dither_path(self):
+        """(ran the specialised dither kernel?, tiles it handed back to the generic kernel) of the last dither pass."""
+        fast, failed = C.c_int32(0), C.c_int32(0)
+        self._check(self._L.nq_get_dither_path(self._h, C.byref(fast), C.byref(failed)))
+        return fast.value, failed.value
 
     @property
     def params(self):

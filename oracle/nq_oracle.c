@@ -945,6 +945,10 @@ static int16_t nearest_lab(nqo_quantizer* q, const int32_t* palette, int K, int3
     return k;
 }
 
+/* event counters (test diagnostics: how often each branch of the per-pixel pass is taken) */
+static int64_t g_dbg[16];
+void nqo_debug_counters(int64_t* out16, int reset) { if (out16) memcpy(out16, g_dbg, sizeof g_dbg); if (reset) memset(g_dbg, 0, sizeof g_dbg); }
+
 /* NQ/PnnLABQuantizer.java:407-474 */
 static int16_t closest_lab(nqo_quantizer* q, const int32_t* palette, int K, int32_t c, int pos, int32_t* out4, int64_t* rng) {
     if (c_alpha(c) <= q->alphaThreshold) { if (out4) out4[0] = out4[1] = out4[2] = out4[3] = -1; return nearest_lab(q, palette, K, c, pos); }
@@ -985,11 +989,14 @@ static int16_t closest_lab(nqo_quantizer* q, const int32_t* palette, int K, int3
     }
     if (out4) { memcpy(out4, closest, sizeof closest); if (!rng) return 0; }
     int idx = 1;
+    g_dbg[1]++; if (closest[2] == 0) g_dbg[7]++; if (closest[2] >= K) g_dbg[8]++;
     if (closest[2] == 0 || (nqo_jrandom_next_int_bound(rng, 32767) % i_add_wrap(closest[3], closest[2])) <= closest[3])
         idx = 0;
     int MAX_ERR = K;
-    if (closest[idx + 2] >= MAX_ERR || closest[idx] == 0 || c_alpha(palette[closest[idx]]) < c_alpha(c))
+    if (closest[idx + 2] >= MAX_ERR || closest[idx] == 0 || c_alpha(palette[closest[idx]]) < c_alpha(c)) {
+        g_dbg[2]++;
         return nearest_lab(q, palette, K, c, pos);
+    }
     return (int16_t) closest[idx];
 }
 
@@ -1185,6 +1192,7 @@ static int ditherPixel(GilbertCurve* g, int x, int y, int32_t c2, float beta) {
     }
     double gamma = (K <= 32 && weight < .01 && weight > .007) ? 1 - beta : beta;
     if (K > 4 && Y_Diff(pixel, c2) > (gamma * acceptedDiff)) {
+        g_dbg[4]++;
         if (g->margin > 6 || gamma > beta) {
             float kappa = sal[bidx] < .4f ? beta * .4f * sal[bidx] : beta * .4f / sal[bidx];
             int32_t c1 = c_argb(a_pix, r_pix, g_pix, b_pix);
@@ -1212,6 +1220,7 @@ static int ditherPixel(GilbertCurve* g, int x, int y, int32_t c2, float beta) {
     if (g->DITHER_MAX < 16 && K > 4 && sal[bidx] < .6f && Y_Diff(pixel, c2) > g->margin - 1)
         c2 = c_argb(a_pix, r_pix, g_pix, b_pix);
     if (K > 32 && sal[bidx] > .95) {
+        g_dbg[5]++;
         float kappa = beta * fmaxf(.05f, .75f - K / 128.0f) * sal[bidx];
         c2 = blue_diffuse(pixel, palette[g->qPixels[bidx]], kappa, strength, x, y);
     }
@@ -1249,8 +1258,10 @@ static void diffusePixel(GilbertCurve* g, int x, int y) {
 
     int32_t c2 = c_argb(a_pix, r_pix, g_pix, b_pix);
     if (sal != NULL && g->dither && !g->sortedByYDiff && (!g->hasAlpha || c_alpha(pixel) < a_pix)) {
-        if ((K >= 256 && sal[bidx] > .99f) || (g->hasAlpha && (c_alpha(pixel) - a_pix) < (.5 * g->margin)))
+        if ((K >= 256 && sal[bidx] > .99f) || (g->hasAlpha && (c_alpha(pixel) - a_pix) < (.5 * g->margin))) {
+            g_dbg[6]++;
             g->qPixels[bidx] = ditherable_nearest(g->dth, palette, K, c2, bidx);
+        }
         else
             g->qPixels[bidx] = ditherPixel(g, x, y, c2, g->beta);
     }
@@ -1282,6 +1293,8 @@ static void diffusePixel(GilbertCurve* g, int x, int y) {
 
     int unaccepted = 0;
     int errLength = denoise ? 3 : 0;
+    g_dbg[0]++;
+    { int any = 0; for (int j = 0; j < errLength; ++j) if (fabsf(error.p[j]) >= g->ditherMax) any = 1; if (any) { g_dbg[3]++; if (diffuse) g_dbg[9]++; } if (maxErr > (float) (g->DITHER_MAX - 1)) g_dbg[10]++; }
     for (int j = 0; j < errLength; ++j) {
         if (fabsf(error.p[j]) >= g->ditherMax) {
             if (g->sortedByYDiff && sal != NULL) unaccepted = 1;
