@@ -9,10 +9,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnquant_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-DEVICE_SOURCES = ["nq_kernels.hip"]
-HOST_SOURCES = ["nq_abi.cpp"]
-DEPS = ["nq_device.h", "nq_kernels.h", "nq_dither.inc", "nq_palette.inc", "nq_merge.inc", "nq_lists.inc",
-        os.path.join("..", "..", "include", "nquant_abi.h"), os.path.join("..", "..", "include", "nq_blue_noise_64x64.inc")]
+INC = os.path.join("..", "..", "include")
+# object -> (kind, sources it is rebuilt for)
+UNITS = {
+    "nq_kernels.hip": ("device", ["nq_kernels.hip", "nq_device.h", "nq_kernels.h", "nq_dither.inc", "nq_palette.inc", "nq_merge.inc", "nq_lists.inc",
+                                  os.path.join(INC, "nq_blue_noise_64x64.inc")]),
+    "nq_dither_fast.hip": ("device", ["nq_dither_fast.hip", "nq_device.h", "nq_kernels.h", os.path.join(INC, "nq_blue_noise_64x64.inc")]),
+    "nq_abi.cpp": ("host", ["nq_abi.cpp", "nq_kernels.h", os.path.join(INC, "nquant_abi.h")]),
+}
 
 
 def _newer(target, sources):
@@ -23,28 +27,31 @@ def _newer(target, sources):
 
 
 def build(force=False, verbose=False):
-    all_src = [os.path.join(CSRC, s) for s in DEVICE_SOURCES + HOST_SOURCES + DEPS] + [os.path.abspath(__file__)]
-    if not force and not _newer(LIB, all_src):
-        return LIB
-    objs = []
-    for s in DEVICE_SOURCES:
-        o = os.path.join(CSRC, s + ".o")
-        cmd = [HIPCC, "--offload-arch=gfx950", "-x", "hip"] + COMMON + ["-c", os.path.join(CSRC, s), "-o", o]
+    """Compiles the translation units whose sources changed (in parallel) and links libnquant_hip.so."""
+    procs, objs = [], []
+    me = os.path.abspath(__file__)
+    for src, (kind, deps) in UNITS.items():
+        o = os.path.join(CSRC, src + ".o")
+        objs.append(o)
+        if not force and not _newer(o, [os.path.join(CSRC, d) for d in deps] + [me]):
+            continue
+        if kind == "device":
+            cmd = [HIPCC, "--offload-arch=gfx950", "-x", "hip"] + COMMON + ["-c", os.path.join(CSRC, src), "-o", o]
+            if os.environ.get("NQ_BUILD_KNOCKOUT"):     # timing experiments (tools/knockout.sh): stages can be left out at run time
+                cmd.insert(-4, "-DNQ_FAST_KNOCKOUT")
+        else:
+            cmd = [HIPCC, "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + COMMON + ["-c", os.path.join(CSRC, src), "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    if procs or force or _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        objs.append(o)
-    for s in HOST_SOURCES:
-        o = os.path.join(CSRC, s + ".o")
-        cmd = [HIPCC, "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + COMMON + ["-c", os.path.join(CSRC, s), "-o", o]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(o)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
     return LIB
 
 

@@ -208,6 +208,7 @@ int use_device(nq_handle* h) {
             gamma[ch] = c < 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
         }
         upload_tables(gamma, std::exp(1.5), std::exp(1.75), h->stream);
+        upload_tables_fast(gamma, std::exp(1.5), std::exp(1.75), h->stream);
         NQ_HIP(h, hipGetLastError());
         NQ_HIP(h, h->d_scalars.reserve(40));
         NQ_HIP(h, h->d_ints.reserve(8 + 64));
@@ -235,7 +236,7 @@ int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
     out->closest = out->closestCount = out->nearest = out->nearestCount = nullptr;
     if (!h->use_lists || P.K > 256 || P.K < 8) return NQ_OK;
     const size_t LB = (size_t) 65536 * 32;
-    NQ_HIP(h, h->sc->cell_lists.reserve(2 * LB + 2 * 65536));
+    NQ_HIP(h, h->sc->cell_lists.reserve(2 * LB + 2 * 65536 + 2 * LB));     // + the packed records of the specialised dither kernel
     unsigned char* base = h->sc->cell_lists.p;
     double wA, wR, wG, wB;
     if (h->kind == NQ_KIND_LAB) {
@@ -681,10 +682,11 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     const int* d_tile_list = nullptr;
     h->last_dither_fast = 0;
     if (!sequential && h->use_fast_dither && gilbert_fast_eligible(P, G, T, lv)) {
-        // production path (nq_dither_fast.inc); the tiles it cannot finish come back as a list for the generic kernel below
+        // production path (nq_dither_fast.hip); the tiles it cannot finish come back as a list for the generic kernel below
         NQ_HIP(h, h->d_failed.reserve((size_t) T.tiles_x * T.tiles_y + 1));
         launch_gilbert_fast(P, G, T, lv, (const int*) d_argb, d_sal, h->d_palette.p, (long long) seed, d_out_index,
-                            post ? nullptr : (int*) d_out_argb, h->d_failed.p, h->stream);
+                            post ? nullptr : (int*) d_out_argb, h->d_failed.p, h->sc->cell_lists.p + 2 * (size_t) 65536 * 32 + 2 * 65536,
+                            h->stream);
         d_tile_list = h->d_failed.p;
         h->last_dither_fast = 1;
     }

@@ -20,7 +20,7 @@ struct ConstTables {
     double exp1_75;        // Math.exp(1.75)  (NQ/PnnLABQuantizer.java:62)
     int8_t blue[4096];     // TELL_BLUE_NOISE (NQ/BlueNoise.java:13-178), data
 };
-extern __constant__ ConstTables g_tab;   // defined in nq_kernels.hip (single translation unit)
+static __constant__ ConstTables g_tab;   // one copy per device translation unit (no relocatable device code): each TU has its upload_tables*()
 
 // struct DevParams: nq_kernels.h
 
@@ -278,6 +278,16 @@ __device__ __forceinline__ int blue_diffuse(int pixel, int qPixel, float weight,
     b_pix = j_d2i(fmin(255.0, fmax((double) (b_pix + (adj * (b_pix - c_blue(qPixel)))), 0.0)));
     a_pix = j_d2i(fmin(255.0, fmax((double) (a_pix + (adj * (a_pix - c_alpha(qPixel)))), 0.0)));
     return c_argb(a_pix, r_pix, g_pix, b_pix);
+}
+
+// GilbertCurve.normalDistribution (NQ/GilbertCurve.java:114-123)
+__device__ __forceinline__ float normalDistribution(float x, float peak) {
+    const float mean = .5f, stdDev = .1f;
+    double exponent = -sqr((double) (x - mean)) / (2 * sqr((double) stdDev));
+    double pdf = (1 / (stdDev * sqrt(2 * NQ_PI))) * exp(exponent);
+    double maxPdf = 1 / (stdDev * sqrt(2 * NQ_PI));
+    double scaledPdf = (pdf / maxPdf) * peak;
+    return (float) fmax(0.0, fmin((double) peak, scaledPdf));
 }
 
 // ---- java.util.Random ---------------------------------------------------------------------------

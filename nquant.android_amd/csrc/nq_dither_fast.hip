@@ -1,3 +1,11 @@
+// nq_dither_fast.hip -- second device translation unit of libnquant_hip.so (gfx950 only): the specialised dither kernel.
+// Build flags as nq_kernels.hip (-ffp-contract=off -fno-fast-math).  Own copy of the constant tables (upload_tables_fast).
+#include "nq_device.h"
+#include "nq_kernels.h"
+#include <cstring>
+#include <cmath>
+#include <cstdlib>
+
 // nq_dither_fast.inc -- the production form of the per-pixel nearest-colour + dither pass for
 // the configuration family the headline benchmark and BASELINE cfg 3-5 use:
 //     PnnLABQuantizer, 32 < K <= 256, no semi-transparency, DITHER_MAX = 25, not sorted-by-yDiff, PARALLEL_TILED.
@@ -34,7 +42,15 @@ struct FastArgs {
     int failedCap;
     int vecOut;              // 1: rows leave as 16-byte (ARGB) / 8-byte (index) stores (tile width, image width and pointers allow it)
     int* failed;             // [0] = number of tiles handed to the generic kernel, [1..] = their indices
+    const uint4* packed;     // [65536][2]: per colour cell {closest list, nearest list} in one 32-byte record (pack_lists_kernel)
+    const uint4* cont;       // [2][65536]: candidates 15..30 of the closest / nearest lists
+    int debug;               // timing experiments only (builds with -DNQ_FAST_KNOCKOUT): bit mask of stages to leave out
 };
+#ifdef NQ_FAST_KNOCKOUT
+#define NQ_KO(bit) (F.debug & (bit))
+#else
+#define NQ_KO(bit) false
+#endif
 
 // initWeights(25) (NQ/GilbertCurve.java:336-354) as bit patterns; the host compares them with its own table
 #define NQ_FAST_W(t) __uint_as_float(k_fast_w25[t])
@@ -45,6 +61,29 @@ static constexpr unsigned k_fast_w25[25] = {
 bool fast_weights_match(const float* w25) {
     for (int i = 0; i < 25; ++i) { unsigned u; std::memcpy(&u, &w25[i], 4); if (u != k_fast_w25[i]) return false; }
     return true;
+}
+
+// One 32-byte record per 5-6-5 colour cell: bytes 0..14 the first closest candidates, byte 15 their number, bytes 16..30 the
+// first nearest candidates, byte 31 their number (255 = the cell needs a full scan or has more than 31 candidates: the tile goes to
+// the generic kernel).  Both lists of a lookup arrive with ONE cache line instead of four (two lists + two counts in separate
+// arrays).  Candidates 15..30 of the few longer lists live in two continuation arrays (16 bytes per cell each).
+__global__ void __launch_bounds__(256) pack_lists_kernel(CellLists L, uint4* __restrict__ out, uint4* __restrict__ cont) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= 65536) return;
+    __align__(16) unsigned char rec[32];
+    __align__(16) unsigned char more[32];
+    for (int half = 0; half < 2; ++half) {
+        const unsigned char* src = (half ? L.nearest : L.closest) + (size_t) cell * NQ_LIST_CAP;
+        const int n = (half ? L.nearestCount : L.closestCount)[cell];
+        const bool ok = n <= 31;
+        for (int i = 0; i < 15; ++i) rec[half * 16 + i] = ok && i < n ? src[i] : 0;
+        rec[half * 16 + 15] = ok ? (unsigned char) n : 255;
+        for (int i = 0; i < 16; ++i) more[half * 16 + i] = ok && 15 + i < n ? src[15 + i] : 0;
+    }
+    const uint4* r = reinterpret_cast<const uint4*>(rec);
+    const uint4* m = reinterpret_cast<const uint4*>(more);
+    out[2 * cell] = r[0]; out[2 * cell + 1] = r[1];
+    cont[cell] = m[0]; cont[65536 + cell] = m[1];
 }
 
 #define NQ_FQ 29           // boxes in the register window: 25 live + 4 appended before the window moves
@@ -171,14 +210,17 @@ __device__ __forceinline__ void lab32_of(int c, const float* __restrict__ g32, f
 }
 
 // exact nearestColorIndex over a candidate list (the list branch of nearest_lab, nq_device.h): f64 reference arithmetic
-__device__ __forceinline__ int fast_nearest_exact(const FastLds& S, int c, unsigned long long w0, unsigned long long w1,
-                                                  unsigned long long w2, unsigned long long w3, int n, int kfirst) {
+__device__ __forceinline__ int fast_nearest_exact(const FastLds& S, int c, uint4 list, const uint4* cont, int n, int kfirst) {
     const Lab lab1 = RGB2LAB_fast(c, S.gamma);
     double mindist = 2147483647.0;
     int k = kfirst;
+    unsigned w0 = list.x, w1 = list.y, w2 = list.z, w3 = list.w;
+#pragma unroll 1
     for (int t = 0; t < n; ++t) {
-        const unsigned long long w = t < 16 ? (t < 8 ? w0 : w1) : (t < 24 ? w2 : w3);
-        const int i = (int) ((w >> ((t & 7) * 8)) & 0xFF);
+        if (t == 15) { const uint4 m = *cont; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
+        const int i = (int) (w0 & 0xFF);
+        w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+        w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
         const float4 l2 = S.lab[i];
         double curdist = (double) fabsf(l2.x - lab1.L);
         if (curdist > mindist) continue;
@@ -352,6 +394,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
 
             float e[4] = {(float) c_red(pixel), (float) c_green(pixel), (float) c_blue(pixel), (float) c_alpha(pixel)};
             float maxErr = 24.0f;               // DITHER_MAX - 1
+            if (!NQ_KO(32))
             switch (u) {
                 case 0: fast_accumulate<0>(q, e, maxErr); break;
                 case 1: fast_accumulate<1>(q, e, maxErr); break;
@@ -367,33 +410,35 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
 
             // :212-229 (K > 32: never branch B)
             int c = c2;
-            if (branchA && !(K >= 256 && sal > .99f)) c = fast_dither_color(S, G, K, xx, yy, c2, pixel, sal);
+            if (branchA && !(K >= 256 && sal > .99f) && !NQ_KO(8)) c = fast_dither_color(S, G, K, xx, yy, c2, pixel, sal);
 
             // ---- Ditherable.nearestColorIndex(palette, c, bidx) = closestColorIndex (K > 4), NQ/PnnLABQuantizer.java:407-474
             int qidx = 0;
             if (c_alpha(c) <= 0xF) failed = true;           // transparent colour: the generic kernel redoes this tile
             else {
-                const int cell = cell_of(c);
-                const int ncl = lists.closestCount[cell];
-                const int nnr = lists.nearestCount[cell];
-                const ulonglong2* lp = reinterpret_cast<const ulonglong2*>(lists.closest + (size_t) cell * NQ_LIST_CAP);
-                const ulonglong2* np = reinterpret_cast<const ulonglong2*>(lists.nearest + (size_t) cell * NQ_LIST_CAP);
-                const ulonglong2 la = lp[0], na = np[0];
-                if (ncl == NQ_LIST_FULLSCAN || nnr == NQ_LIST_FULLSCAN) failed = true;
-                const int n1 = ncl == NQ_LIST_FULLSCAN ? 0 : ncl, n2 = nnr == NQ_LIST_FULLSCAN ? 0 : nnr;
+                const int cell = NQ_KO(1) ? 0 : cell_of(c);
+                const uint4 la = F.packed[2 * cell], na = F.packed[2 * cell + 1];
+                const int ncl = (int) (la.w >> 24), nnr = (int) (na.w >> 24);
+                if (ncl == 255 || nnr == 255) failed = true;
+                const int n1 = (ncl == 255 || NQ_KO(16)) ? 0 : ncl, n2 = nnr == 255 ? 0 : nnr;
                 const int cr = c_red(c), cg = c_green(c), cb = c_blue(c);
                 const float crf = (float) cr, cgf = (float) cg, cbf = (float) cb;
                 FastClosest t; t.c0 = t.c1 = 0; t.e0 = t.e1 = 2147483647;
                 {
-                    // the list as a 16-byte shift register: entry i is the low byte after i shifts
-                    unsigned w0 = (unsigned) la.x, w1 = (unsigned) (la.x >> 32), w2 = (unsigned) la.y, w3 = (unsigned) (la.y >> 32);
+                    // the list as a 16-byte shift register: entry i is the low byte after i shifts; the palette word of entry
+                    // i + 1 is requested from LDS before entry i is evaluated
+                    unsigned w0 = la.x, w1 = la.y, w2 = la.z, w3 = la.w;
+                    int k_next = (int) (w0 & 0xFF);
+                    int c2_next = S.argb[k_next];
 #pragma unroll 1
                     for (int i = 0; i < n1; ++i) {
-                        if (i == 16) { const ulonglong2 lb = lp[1]; w0 = (unsigned) lb.x; w1 = (unsigned) (lb.x >> 32); w2 = (unsigned) lb.y; w3 = (unsigned) (lb.y >> 32); }
-                        const int k = (int) (w0 & 0xFF);
+                        const int k = k_next, c2k = c2_next;
                         w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
                         w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
-                        fast_closest_step(t, k, S.argb[k], crf, cgf, cbf, cr, cg, cb, F.qa, F.qb, F.qc, wr, wg, wb, ratio);
+                        if (i == 14 && n1 > 15) { const uint4 m = F.cont[cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
+                        k_next = (int) (w0 & 0xFF);
+                        c2_next = S.argb[k_next];
+                        fast_closest_step(t, k, c2k, crf, cgf, cbf, cr, cg, cb, F.qa, F.qb, F.qc, wr, wg, wb, ratio);
                     }
                 }
                 if (t.e1 == 2147483647) t.c1 = t.c0;
@@ -422,7 +467,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                 }
                 const int ci = idx ? t.c1 : t.c0, ei = idx ? t.e1 : t.e0;
                 qidx = ci;
-                if (ei >= K || ci == 0 || c_alpha(S.argb[ci]) < c_alpha(c)) {
+                if ((ei >= K || ci == 0 || c_alpha(S.argb[ci]) < c_alpha(c)) && !NQ_KO(2)) {
                     // ---- nearestColorIndex (cache-miss semantics), K > 32: argmin of |dL| + sqrt(dA^2 + dB^2), ties to the higher index
                     const int kfirst = P.hasAlpha ? 1 : 0;                   // (alpha > 0xF here)
                     float L1, A1, B1;
@@ -430,14 +475,18 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                     float d1 = 3.0e38f, d2 = 3.0e38f;
                     int k1 = kfirst;
                     {
-                        unsigned w0 = (unsigned) na.x, w1 = (unsigned) (na.x >> 32), w2 = (unsigned) na.y, w3 = (unsigned) (na.y >> 32);
-                        const int n2a = min(n2, 16);            // longer lists (rare) are decided by the exact scan below
+                        unsigned w0 = na.x, w1 = na.y, w2 = na.z, w3 = na.w;
+                        int k_next = (int) (w0 & 0xFF);
+                        float4 l_next = S.lab[k_next];
 #pragma unroll 1
-                        for (int i = 0; i < n2a; ++i) {
-                            const int k = (int) (w0 & 0xFF);
+                        for (int i = 0; i < n2; ++i) {
+                            const int k = k_next;
+                            const float4 l2 = l_next;
                             w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
                             w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
-                            const float4 l2 = S.lab[k];
+                            if (i == 14 && n2 > 15) { const uint4 m = F.cont[65536 + cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
+                            k_next = (int) (w0 & 0xFF);
+                            l_next = S.lab[k_next];
                             const float dA = l2.y - A1, dB = l2.z - B1;
                             const float d = fabsf(l2.x - L1) + __builtin_amdgcn_sqrtf(__builtin_fmaf(dA, dA, dB * dB));
                             const bool lt = d < d1;
@@ -447,11 +496,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                         }
                     }
                     qidx = k1;
-                    if (n2 > 16 || !(d2 - d1 > 2.0f * NQ_FAST_NEAR_EPS)) {
-                        ulonglong2 nb; nb.x = nb.y = 0;
-                        if (n2 > 16) nb = np[1];
-                        qidx = fast_nearest_exact(S, c, na.x, na.y, nb.x, nb.y, n2, kfirst);
-                    }
+                    if (!(d2 - d1 > 2.0f * NQ_FAST_NEAR_EPS)) qidx = fast_nearest_exact(S, c, na, F.cont + 65536 + cell, n2, kfirst);
                 }
             }
 
@@ -466,7 +511,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                 float ea = e[0], eb = e[1], ec = e[2];
 #pragma unroll 1
                 for (int j = 0; j < 3; ++j) {
-                    if (fabsf(ea) >= ditherMaxF) {
+                    if (fabsf(ea) >= ditherMaxF && !NQ_KO(4)) {
                         if (diffuse) ea = tanh_to_float(ea / maxErr * 20) * ditherMax1;
                         else if (illusionAll) ea = (ea / maxErr) * ditherMax1;      // (float) ((double) (e / maxErr) * 1.0) * (ditherMax - 1)
                         else ea /= F.limiterDiv;
@@ -543,5 +588,73 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
         }
     }
 }
+
+} // namespace nq
+
+namespace nq {
+
+static const int8_t h_blue_fast[4096] = {
+#include "../../include/nq_blue_noise_64x64.inc"
+};
+void upload_tables_fast(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s) {
+    static ConstTables t;     // host staging must outlive the async copy
+    for (int i = 0; i < 256; ++i) t.gamma[i] = gamma[i];
+    t.exp1_5 = exp1_5; t.exp1_75 = exp1_75;
+    for (int i = 0; i < 4096; ++i) t.blue[i] = h_blue_fast[i];
+    (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tab), &t, sizeof t, 0, hipMemcpyHostToDevice, s);
+    (void) hipStreamSynchronize(s);
+}
+
+static inline CellLists to_lists_fast(const ListsView& v) {
+    CellLists l; l.closest = v.closest; l.closestCount = v.closestCount; l.nearest = v.nearest; l.nearestCount = v.nearestCount;
+    return l;
+}
+
+// The specialised kernel of nq_dither_fast.inc, when the configuration is inside its domain (returns false otherwise: the caller
+// runs the generic kernel on every tile).  d_failed: int[1 + tiles] -- the tiles it hands back ({count, indices}); the caller
+// then runs the generic kernel over that list.
+bool gilbert_fast_eligible(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv) {
+    const int tilepx = T.tile_w * T.tile_h;
+    return P.kind == 1 && P.K > 32 && P.K <= 256 && !P.hasSemi && !P.rewriteA0 && !G.sortedByYDiff && !G.hasAlphaW && G.DITHER_MAX == 25 &&
+           fast_weights_match(G.weights) && lv.closest && lv.nearest && P.ratio >= 0 && tilepx >= 1 && tilepx <= 1024 &&
+           fast_lds_bytes(tilepx, fast_stride_bytes(tilepx)) <= 160 * 1024 - 512;
+}
+void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
+                         const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
+                         int* d_failed, void* d_packed, hipStream_t s) {
+    const int ntiles = T.tiles_x * T.tiles_y;
+    const int tilepx = T.tile_w * T.tile_h;
+    FastArgs F;
+    // err of NQ/PnnLABQuantizer.java:421-445 as a quadratic form (every YUV term is (coeff * d)^2)
+    double sq[3] = {0, 0, 0};
+    static const float kc[3][3] = {{0.299f, 0.587f, 0.114f}, {-0.14713f, -0.28886f, 0.436f}, {0.615f, -0.51499f, -0.10001f}};
+    for (int i = 0; i < 3; ++i) for (int c = 0; c < 3; ++c) sq[c] += (double) kc[i][c] * (double) kc[i][c];
+    F.qa = (float) (P.PR * (1 - P.ratio) + P.ratio * sq[0]);
+    F.qb = (float) (P.PG * (1 - P.ratio) + P.ratio * sq[1]);
+    F.qc = (float) (P.PB * (1 - P.ratio) + P.ratio * sq[2]);
+    F.limiterDiv = (float) (1 + std::sqrt((double) G.ditherMax));
+    F.strideBytes = fast_stride_bytes(tilepx);
+    F.failedCap = ntiles;
+    F.failed = d_failed;
+    F.packed = (const uint4*) d_packed;
+    F.cont = F.packed + 2 * 65536;
+    hipLaunchKernelGGL(pack_lists_kernel, dim3(65536 / 256), dim3(256), 0, s, to_lists_fast(lv), (uint4*) d_packed, (uint4*) d_packed + 2 * 65536);
+    F.debug = 0;
+#ifdef NQ_FAST_KNOCKOUT
+    if (const char* e = std::getenv("NQ_FAST_DEBUG")) F.debug = std::atoi(e);
+#endif
+    F.vecOut = (T.tile_w % 4 == 0) && (T.width % 4 == 0) && ((uintptr_t) d_index % 8 == 0) && (!d_argb || (uintptr_t) d_argb % 16 == 0);
+    (void) hipMemsetAsync(d_failed, 0, sizeof(int), s);
+    const size_t lds = fast_lds_bytes(tilepx, F.strideBytes);
+    const int grid = (ntiles + 255) / 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void*) gilbert_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gilbert_fast_kernel<2>), dim3(grid), dim3(256), lds, s, P, G, T, to_lists_fast(lv), F, d_pixels, d_saliency, d_palette,
+                       seed, d_index, d_argb);
+}
+
 
 } // namespace nq

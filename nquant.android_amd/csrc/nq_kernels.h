@@ -41,7 +41,8 @@ struct TileGeom {
     int shape_w[4], shape_h[4];
 };
 
-void upload_tables(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s);
+void upload_tables(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s);        // nq_kernels.hip's copy
+void upload_tables_fast(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s);   // nq_dither_fast.hip's copy
 
 // candidate lists per 5-6-5 colour cell (nq_lists.inc); null pointers = full palette scans
 struct ListsView {
@@ -69,11 +70,11 @@ void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& 
                     int* d_log, int* d_log_count, unsigned char* d_seen, int log_cap,
                     // nullable: {count, tile indices...} -- walk only these tiles (the ones gilbert_fast_kernel handed back)
                     const int* d_tile_list, hipStream_t s);
-// nq_dither_fast.inc: the specialised kernel for LAB, 32 < K <= 256, no semi-transparency, DITHER_MAX 25, tiled
+// nq_dither_fast.hip: the specialised kernel for LAB, 32 < K <= 256, no semi-transparency, DITHER_MAX 25, tiled
 bool gilbert_fast_eligible(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv);
 void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
                          const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
-                         int* d_failed /* int[1 + tiles] */, hipStream_t s);
+                         int* d_failed /* int[1 + tiles] */, void* d_packed /* 65536 x 64 bytes */, hipStream_t s);
 // BlueNoise.dither post-pass (NQ/BlueNoise.java:207-222); in-place on d_index, writes d_argb
 void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,
                       float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,

@@ -7,13 +7,8 @@
 #include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 
-namespace nq {
-__constant__ ConstTables g_tab;
-}
-
 #include "nq_lists.inc"
 #include "nq_dither.inc"
-#include "nq_dither_fast.inc"
 #include "nq_palette.inc"
 
 namespace nq {
@@ -112,45 +107,6 @@ void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& 
         launch_gilbert_t<false, 16>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, d_tile_list, s);
     else
         launch_gilbert_t<false, 9>(P, G, T, L, d_pixels, d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, d_tile_list, s);
-}
-
-// The specialised kernel of nq_dither_fast.inc, when the configuration is inside its domain (returns false otherwise: the caller
-// runs the generic kernel on every tile).  d_failed: int[1 + tiles] -- the tiles it hands back ({count, indices}); the caller
-// then runs the generic kernel over that list.
-bool gilbert_fast_eligible(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv) {
-    const int tilepx = T.tile_w * T.tile_h;
-    return P.kind == 1 && P.K > 32 && P.K <= 256 && !P.hasSemi && !P.rewriteA0 && !G.sortedByYDiff && !G.hasAlphaW && G.DITHER_MAX == 25 &&
-           fast_weights_match(G.weights) && lv.closest && lv.nearest && P.ratio >= 0 && tilepx >= 1 && tilepx <= 1024 &&
-           fast_lds_bytes(tilepx, fast_stride_bytes(tilepx)) <= 160 * 1024 - 512;
-}
-void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
-                         const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
-                         int* d_failed, hipStream_t s) {
-    const int ntiles = T.tiles_x * T.tiles_y;
-    const int tilepx = T.tile_w * T.tile_h;
-    FastArgs F;
-    // err of NQ/PnnLABQuantizer.java:421-445 as a quadratic form (every YUV term is (coeff * d)^2)
-    double sq[3] = {0, 0, 0};
-    static const float kc[3][3] = {{0.299f, 0.587f, 0.114f}, {-0.14713f, -0.28886f, 0.436f}, {0.615f, -0.51499f, -0.10001f}};
-    for (int i = 0; i < 3; ++i) for (int c = 0; c < 3; ++c) sq[c] += (double) kc[i][c] * (double) kc[i][c];
-    F.qa = (float) (P.PR * (1 - P.ratio) + P.ratio * sq[0]);
-    F.qb = (float) (P.PG * (1 - P.ratio) + P.ratio * sq[1]);
-    F.qc = (float) (P.PB * (1 - P.ratio) + P.ratio * sq[2]);
-    F.limiterDiv = (float) (1 + std::sqrt((double) G.ditherMax));
-    F.strideBytes = fast_stride_bytes(tilepx);
-    F.failedCap = ntiles;
-    F.failed = d_failed;
-    F.vecOut = (T.tile_w % 4 == 0) && (T.width % 4 == 0) && ((uintptr_t) d_index % 8 == 0) && (!d_argb || (uintptr_t) d_argb % 16 == 0);
-    (void) hipMemsetAsync(d_failed, 0, sizeof(int), s);
-    const size_t lds = fast_lds_bytes(tilepx, F.strideBytes);
-    const int grid = (ntiles + 255) / 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void*) gilbert_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gilbert_fast_kernel<2>), dim3(grid), dim3(256), lds, s, P, G, T, to_lists(lv), F, d_pixels, d_saliency, d_palette,
-                       seed, d_index, d_argb);
 }
 
 void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,

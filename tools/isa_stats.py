@@ -9,13 +9,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "build", "isa")
-SRC = os.path.join(ROOT, "nquant.android_amd", "csrc", "nq_kernels.hip")
-ASM = os.path.join(OUT, "nq_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+CSRC = os.path.join(ROOT, "nquant.android_amd", "csrc")
 
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     pat = args[0] if args else "gilbert_fast"
+    unit = "nq_dither_fast" if "fast" in pat else "nq_kernels"
+    SRC = os.path.join(CSRC, unit + ".hip")
+    ASM = os.path.join(OUT, unit + "-hip-amdgcn-amd-amdhsa-gfx950.s")
     if "--nobuild" not in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-x", "hip", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
