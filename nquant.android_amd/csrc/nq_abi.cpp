@@ -265,6 +265,9 @@ int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
     return NQ_OK;
 }
 
+// the packed list records of the specialised kernels (nq_dither_fast.hip) live behind the lists and their counts
+void* packed_lists(nq_handle* h) { return h->sc->cell_lists.p + 2 * (size_t) 65536 * 32 + 2 * 65536; }
+
 int get_path(nq_handle* h, int w, int hgt, const uint32_t** out) {
     auto key = std::make_pair(w, hgt);
     auto it = h->paths.find(key);
@@ -602,7 +605,10 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         nq::ListsView lv;
         int rcl = prepare_lists(h, P, &lv);
         if (rcl) return rcl;
-        launch_lookup_only(P, h->d_palette.p, lv, (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
+        if (h->use_fast_dither && fast_lookup_eligible(P, lv))
+            launch_fast_lookup_only(P, lv, h->d_palette.p, packed_lists(h), (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
+        else
+            launch_lookup_only(P, h->d_palette.p, lv, (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
         NQ_HIP(h, hipGetLastError());
         return NQ_OK;
     }
@@ -685,8 +691,7 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         // production path (nq_dither_fast.hip); the tiles it cannot finish come back as a list for the generic kernel below
         NQ_HIP(h, h->d_failed.reserve((size_t) T.tiles_x * T.tiles_y + 1));
         launch_gilbert_fast(P, G, T, lv, (const int*) d_argb, d_sal, h->d_palette.p, (long long) seed, d_out_index,
-                            post ? nullptr : (int*) d_out_argb, h->d_failed.p, h->sc->cell_lists.p + 2 * (size_t) 65536 * 32 + 2 * 65536,
-                            h->stream);
+                            post ? nullptr : (int*) d_out_argb, h->d_failed.p, packed_lists(h), h->stream);
         d_tile_list = h->d_failed.p;
         h->last_dither_fast = 1;
     }
@@ -1078,7 +1083,10 @@ int nq_nearest_index(nq_handle* h, const uint32_t* palette, int K, const uint32_
     nq::ListsView lv;
     rc = prepare_lists(h, P, &lv);
     if (rc) return rc;
-    launch_nearest_index(P, h->d_palette.p, lv, h->d_colors.p, M, h->d_short.p, h->stream);
+    if (h->use_fast_dither && fast_lookup_eligible(P, lv))
+        launch_fast_nearest_index(P, lv, h->d_palette.p, packed_lists(h), h->d_colors.p, M, h->d_short.p, h->stream);
+    else
+        launch_nearest_index(P, h->d_palette.p, lv, h->d_colors.p, M, h->d_short.p, h->stream);
     NQ_HIP(h, hipGetLastError());
     NQ_HIP(h, hipMemcpyAsync(out_index, h->d_short.p, (size_t) M * sizeof(short), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -1098,7 +1106,10 @@ int nq_closest_tuple(nq_handle* h, const uint32_t* palette, int K, const uint32_
     nq::ListsView lv;
     rc = prepare_lists(h, P, &lv);
     if (rc) return rc;
-    launch_closest_tuple(P, h->d_palette.p, lv, h->d_colors.p, M, h->d_tuple.p, h->stream);
+    if (h->use_fast_dither && fast_lookup_eligible(P, lv))
+        launch_fast_closest_tuple(P, lv, h->d_palette.p, packed_lists(h), h->d_colors.p, M, h->d_tuple.p, h->stream);
+    else
+        launch_closest_tuple(P, h->d_palette.p, lv, h->d_colors.p, M, h->d_tuple.p, h->stream);
     NQ_HIP(h, hipGetLastError());
     NQ_HIP(h, hipMemcpyAsync(out_closest4, h->d_tuple.p, (size_t) 4 * M * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));

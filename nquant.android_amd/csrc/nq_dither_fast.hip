@@ -232,6 +232,70 @@ __device__ __forceinline__ int fast_nearest_exact(const FastLds& S, int c, uint4
     return k;
 }
 
+// uniform context of the two lookups
+struct FastLookup {
+    const uint4* packed;     // FastArgs::packed
+    const uint4* cont;       // FastArgs::cont
+    float qa, qb, qc;        // closest quadratic form (float32)
+    double wr, wg, wb, ratio;   // the reference's own weights PR (1 - ratio) ... for the exact evaluation
+    int kfirst;              // first index of the nearest scan for a visible colour: 1 when palette[0] is the transparent colour
+};
+
+// closest[] of NQ/PnnLABQuantizer.java:415-461 for the colour c (alpha > 0xF) over the n1 listed candidates of its cell.
+// The list is a 16-byte shift register: entry i is the low byte after i shifts; the palette word of entry i + 1 is requested from
+// LDS before entry i is evaluated.
+__device__ __forceinline__ FastClosest fast_closest_tuple(const FastLds& S, const FastLookup& X, int c, uint4 la, int n1, int cell) {
+    const int cr = c_red(c), cg = c_green(c), cb = c_blue(c);
+    const float crf = (float) cr, cgf = (float) cg, cbf = (float) cb;
+    FastClosest t; t.c0 = t.c1 = 0; t.e0 = t.e1 = 2147483647;
+    unsigned w0 = la.x, w1 = la.y, w2 = la.z, w3 = la.w;
+    int k_next = (int) (w0 & 0xFF);
+    int c2_next = S.argb[k_next];
+#pragma unroll 1
+    for (int i = 0; i < n1; ++i) {
+        const int k = k_next, c2k = c2_next;
+        w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+        w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
+        if (i == 14 && n1 > 15) { const uint4 m = X.cont[cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
+        k_next = (int) (w0 & 0xFF);
+        c2_next = S.argb[k_next];
+        fast_closest_step(t, k, c2k, crf, cgf, cbf, cr, cg, cb, X.qa, X.qb, X.qc, X.wr, X.wg, X.wb, X.ratio);
+    }
+    if (t.e1 == 2147483647) t.c1 = t.c0;
+    return t;
+}
+
+// nearestColorIndex (cache-miss semantics) of a visible colour for K > 32 (NQ/PnnLABQuantizer.java:369-375): argmin of
+// |dL| + sqrt(dA^2 + dB^2) over the n2 listed candidates, ties to the higher index.  float32 first (lab32_of); the exact f64 scan
+// decides when the runner-up is within 2 NQ_FAST_NEAR_EPS.
+__device__ __forceinline__ int fast_nearest(const FastLds& S, const FastLookup& X, int c, uint4 na, int n2, int cell) {
+    float L1, A1, B1;
+    lab32_of(c, S.gamma32, L1, A1, B1);
+    float d1 = 3.0e38f, d2 = 3.0e38f;
+    int k1 = X.kfirst;
+    unsigned w0 = na.x, w1 = na.y, w2 = na.z, w3 = na.w;
+    int k_next = (int) (w0 & 0xFF);
+    float4 l_next = S.lab[k_next];
+#pragma unroll 1
+    for (int i = 0; i < n2; ++i) {
+        const int k = k_next;
+        const float4 l2 = l_next;
+        w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+        w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
+        if (i == 14 && n2 > 15) { const uint4 m = X.cont[65536 + cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
+        k_next = (int) (w0 & 0xFF);
+        l_next = S.lab[k_next];
+        const float dA = l2.y - A1, dB = l2.z - B1;
+        const float d = fabsf(l2.x - L1) + __builtin_amdgcn_sqrtf(__builtin_fmaf(dA, dA, dB * dB));
+        const bool lt = d < d1;
+        d2 = lt ? d1 : fminf(d2, d);
+        k1 = lt ? k : k1;
+        d1 = fminf(d1, d);
+    }
+    if (!(d2 - d1 > 2.0f * NQ_FAST_NEAR_EPS)) k1 = fast_nearest_exact(S, c, na, X.cont + 65536 + cell, n2, X.kfirst);
+    return k1;
+}
+
 // Y_Diff(c1, c2) > thr (gt) or < thr (!gt), NQ/CIELABConvertor.java:215-227.  float32 first: each luminance is within 4e-7 of
 // its f64 value (table entries 6e-8 relative, three products, two sums, Y <= 1), the difference times 100 within 1e-4.
 __device__ __forceinline__ bool fast_ydiff_cmp(const FastLds& S, int c1, int c2, double thr, bool gt) {
@@ -356,8 +420,10 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
     long long rng = jr_seed((long long) mix64((unsigned long long) seed + (unsigned long long) tile));
     const bool branchA = G.hasSaliencies && G.dither;                      // (!hasAlphaW: no semi-transparency here)
     const bool hasSal = G.hasSaliencies != 0;
-    const double ratio = P.ratio;
-    const double wr = P.PR * (1 - ratio), wg = P.PG * (1 - ratio), wb = P.PB * (1 - ratio);
+    FastLookup X;
+    X.packed = F.packed; X.cont = F.cont; X.qa = F.qa; X.qb = F.qb; X.qc = F.qc;
+    X.ratio = P.ratio; X.wr = P.PR * (1 - P.ratio); X.wg = P.PG * (1 - P.ratio); X.wb = P.PB * (1 - P.ratio);
+    X.kfirst = P.hasAlpha ? 1 : 0;
     const float ditherMaxF = (float) G.ditherMax, ditherMax1 = (float) (G.ditherMax - 1);
     const bool illusionAll = S.blue[0] > G.thresold;                      // yDiff == 1: TELL_BLUE_NOISE[(int) 4096.0 & 4095]
     bool failed = false;
@@ -417,31 +483,11 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
             if (c_alpha(c) <= 0xF) failed = true;           // transparent colour: the generic kernel redoes this tile
             else {
                 const int cell = NQ_KO(1) ? 0 : cell_of(c);
-                const uint4 la = F.packed[2 * cell], na = F.packed[2 * cell + 1];
+                const uint4 la = X.packed[2 * cell], na = X.packed[2 * cell + 1];
                 const int ncl = (int) (la.w >> 24), nnr = (int) (na.w >> 24);
                 if (ncl == 255 || nnr == 255) failed = true;
                 const int n1 = (ncl == 255 || NQ_KO(16)) ? 0 : ncl, n2 = nnr == 255 ? 0 : nnr;
-                const int cr = c_red(c), cg = c_green(c), cb = c_blue(c);
-                const float crf = (float) cr, cgf = (float) cg, cbf = (float) cb;
-                FastClosest t; t.c0 = t.c1 = 0; t.e0 = t.e1 = 2147483647;
-                {
-                    // the list as a 16-byte shift register: entry i is the low byte after i shifts; the palette word of entry
-                    // i + 1 is requested from LDS before entry i is evaluated
-                    unsigned w0 = la.x, w1 = la.y, w2 = la.z, w3 = la.w;
-                    int k_next = (int) (w0 & 0xFF);
-                    int c2_next = S.argb[k_next];
-#pragma unroll 1
-                    for (int i = 0; i < n1; ++i) {
-                        const int k = k_next, c2k = c2_next;
-                        w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
-                        w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
-                        if (i == 14 && n1 > 15) { const uint4 m = F.cont[cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
-                        k_next = (int) (w0 & 0xFF);
-                        c2_next = S.argb[k_next];
-                        fast_closest_step(t, k, c2k, crf, cgf, cbf, cr, cg, cb, F.qa, F.qb, F.qc, wr, wg, wb, ratio);
-                    }
-                }
-                if (t.e1 == 2147483647) t.c1 = t.c0;
+                const FastClosest t = fast_closest_tuple(S, X, c, la, n1, cell);
                 // :465-468
                 int idx = 1;
                 if (t.e0 == 0) idx = 0;
@@ -468,35 +514,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                 const int ci = idx ? t.c1 : t.c0, ei = idx ? t.e1 : t.e0;
                 qidx = ci;
                 if ((ei >= K || ci == 0 || c_alpha(S.argb[ci]) < c_alpha(c)) && !NQ_KO(2)) {
-                    // ---- nearestColorIndex (cache-miss semantics), K > 32: argmin of |dL| + sqrt(dA^2 + dB^2), ties to the higher index
-                    const int kfirst = P.hasAlpha ? 1 : 0;                   // (alpha > 0xF here)
-                    float L1, A1, B1;
-                    lab32_of(c, S.gamma32, L1, A1, B1);
-                    float d1 = 3.0e38f, d2 = 3.0e38f;
-                    int k1 = kfirst;
-                    {
-                        unsigned w0 = na.x, w1 = na.y, w2 = na.z, w3 = na.w;
-                        int k_next = (int) (w0 & 0xFF);
-                        float4 l_next = S.lab[k_next];
-#pragma unroll 1
-                        for (int i = 0; i < n2; ++i) {
-                            const int k = k_next;
-                            const float4 l2 = l_next;
-                            w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
-                            w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
-                            if (i == 14 && n2 > 15) { const uint4 m = F.cont[65536 + cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
-                            k_next = (int) (w0 & 0xFF);
-                            l_next = S.lab[k_next];
-                            const float dA = l2.y - A1, dB = l2.z - B1;
-                            const float d = fabsf(l2.x - L1) + __builtin_amdgcn_sqrtf(__builtin_fmaf(dA, dA, dB * dB));
-                            const bool lt = d < d1;
-                            d2 = lt ? d1 : fminf(d2, d);
-                            k1 = lt ? k : k1;
-                            d1 = fminf(d1, d);
-                        }
-                    }
-                    qidx = k1;
-                    if (!(d2 - d1 > 2.0f * NQ_FAST_NEAR_EPS)) qidx = fast_nearest_exact(S, c, na, F.cont + 65536 + cell, n2, kfirst);
+                    qidx = fast_nearest(S, X, c, na, n2, cell);
                 }
             }
 
@@ -589,6 +607,91 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same two lookups as stand-alone kernels behind nq_nearest_index / nq_closest_tuple / LOOKUP_ONLY (BASELINE cfg 2): the
+// pure functions of SURVEY 8b, so that the float32 filters of the dither kernel are checked against the oracle colour by colour
+// (tests: the whole 2^24 colour cube).  Colours the filters do not cover (alpha <= 0xF, cells without a packed list) take the
+// generic functions of nq_device.h.
+// ------------------------------------------------------------------------------------------------
+struct FastLookupLds { FastLds S; PalView pal; };
+__device__ __forceinline__ FastLookupLds fast_stage_lookup(const DevParams& P, const int* __restrict__ g_palette) {
+    __shared__ __align__(16) int s_argb[256];
+    __shared__ __align__(16) float4 s_lab[256];
+    __shared__ __align__(16) double s_gamma[256];
+    __shared__ float s_gamma32[256];
+    __shared__ float s_L[256], s_A[256], s_B[256];
+    const int tid = threadIdx.x;
+    const int c2 = tid < P.K ? g_palette[tid] : 0;
+    s_argb[tid] = c2;
+    const Lab l2 = RGB2LAB(c2);
+    s_lab[tid] = make_float4(l2.L, l2.A, l2.B, 0.f);
+    s_L[tid] = l2.L; s_A[tid] = l2.A; s_B[tid] = l2.B;
+    s_gamma[tid] = g_tab.gamma[tid];
+    s_gamma32[tid] = (float) g_tab.gamma[tid];
+    __syncthreads();
+    FastLookupLds r;
+    r.S.argb = s_argb; r.S.lab = s_lab; r.S.gamma = s_gamma; r.S.gamma32 = s_gamma32; r.S.blue = g_tab.blue; r.S.path = nullptr;
+    r.S.tileinfo = nullptr; r.S.stage = nullptr;
+    r.pal.argb = s_argb; r.pal.L = s_L; r.pal.A = s_A; r.pal.B = s_B; r.pal.gamma = s_gamma; r.pal.blue = g_tab.blue;
+    return r;
+}
+__device__ __forceinline__ FastLookup fast_lookup_ctx(const DevParams& P, const FastArgs& F) {
+    FastLookup X;
+    X.packed = F.packed; X.cont = F.cont; X.qa = F.qa; X.qb = F.qb; X.qc = F.qc;
+    X.ratio = P.ratio; X.wr = P.PR * (1 - P.ratio); X.wg = P.PG * (1 - P.ratio); X.wb = P.PB * (1 - P.ratio);
+    X.kfirst = P.hasAlpha ? 1 : 0;
+    return X;
+}
+__device__ __forceinline__ int fast_nearest_any(const DevParams& P, const FastLookupLds& T, const FastLookup& X, const CellLists& lists, int c) {
+    if (c_alpha(c) > 0xF) {
+        const int cell = cell_of(c);
+        const uint4 na = X.packed[2 * cell + 1];
+        const int n = (int) (na.w >> 24);
+        if (n != 255) return fast_nearest(T.S, X, c, na, n, cell);
+    }
+    return nearest_lab(P, T.pal, c, &lists);
+}
+__global__ void __launch_bounds__(256) fast_nearest_index_kernel(DevParams P, CellLists lists, FastArgs F, const int* __restrict__ g_palette,
+                                                                 const int* __restrict__ colors, long long M, short* __restrict__ out) {
+    const FastLookupLds T = fast_stage_lookup(P, g_palette);
+    const FastLookup X = fast_lookup_ctx(P, F);
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long) gridDim.x * blockDim.x)
+        out[i] = (short) fast_nearest_any(P, T, X, lists, colors[i]);
+}
+__global__ void __launch_bounds__(256) fast_lookup_only_kernel(DevParams P, CellLists lists, FastArgs F, const int* __restrict__ g_palette,
+                                                               const int* __restrict__ pixels, long long N,
+                                                               unsigned short* __restrict__ out_index, int* __restrict__ out_argb) {
+    const FastLookupLds T = fast_stage_lookup(P, g_palette);
+    const FastLookup X = fast_lookup_ctx(P, F);
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long) gridDim.x * blockDim.x) {
+        const int k = fast_nearest_any(P, T, X, lists, pixels[i]);          // (nMaxColors > 32 here: no alpha-0 rewrite)
+        if (out_index) out_index[i] = (unsigned short) k;
+        if (out_argb) out_argb[i] = T.S.argb[k];
+    }
+}
+__global__ void __launch_bounds__(256) fast_closest_tuple_kernel(DevParams P, CellLists lists, FastArgs F, const int* __restrict__ g_palette,
+                                                                 const int* __restrict__ colors, long long M, int* __restrict__ out4) {
+    const FastLookupLds T = fast_stage_lookup(P, g_palette);
+    const FastLookup X = fast_lookup_ctx(P, F);
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long) gridDim.x * blockDim.x) {
+        const int c = colors[i];
+        int closest[4];
+        if (c_alpha(c) <= 0xF) closest[0] = closest[1] = closest[2] = closest[3] = -1;
+        else {
+            const int cell = cell_of(c);
+            const uint4 la = X.packed[2 * cell];
+            const int n = (int) (la.w >> 24);
+            if (n != 255) {
+                const FastClosest t = fast_closest_tuple(T.S, X, c, la, n, cell);
+                closest[0] = t.c0; closest[1] = t.c1; closest[2] = t.e0; closest[3] = t.e1;
+            }
+            else closest_tuple_lab(P, T.pal, c, closest, &lists);
+        }
+        reinterpret_cast<int4*>(out4)[i] = make_int4(closest[0], closest[1], closest[2], closest[3]);
+    }
+}
+
 } // namespace nq
 
 namespace nq {
@@ -619,12 +722,9 @@ bool gilbert_fast_eligible(const DevParams& P, const GilbertConsts& G, const Til
            fast_weights_match(G.weights) && lv.closest && lv.nearest && P.ratio >= 0 && tilepx >= 1 && tilepx <= 1024 &&
            fast_lds_bytes(tilepx, fast_stride_bytes(tilepx)) <= 160 * 1024 - 512;
 }
-void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
-                         const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
-                         int* d_failed, void* d_packed, hipStream_t s) {
-    const int ntiles = T.tiles_x * T.tiles_y;
-    const int tilepx = T.tile_w * T.tile_h;
+static FastArgs fast_args(const DevParams& P, const ListsView& lv, void* d_packed, hipStream_t s) {
     FastArgs F;
+    std::memset(&F, 0, sizeof F);
     // err of NQ/PnnLABQuantizer.java:421-445 as a quadratic form (every YUV term is (coeff * d)^2)
     double sq[3] = {0, 0, 0};
     static const float kc[3][3] = {{0.299f, 0.587f, 0.114f}, {-0.14713f, -0.28886f, 0.436f}, {0.615f, -0.51499f, -0.10001f}};
@@ -632,14 +732,21 @@ void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileG
     F.qa = (float) (P.PR * (1 - P.ratio) + P.ratio * sq[0]);
     F.qb = (float) (P.PG * (1 - P.ratio) + P.ratio * sq[1]);
     F.qc = (float) (P.PB * (1 - P.ratio) + P.ratio * sq[2]);
+    F.packed = (const uint4*) d_packed;
+    F.cont = F.packed + 2 * 65536;
+    hipLaunchKernelGGL(pack_lists_kernel, dim3(65536 / 256), dim3(256), 0, s, to_lists_fast(lv), (uint4*) d_packed, (uint4*) d_packed + 2 * 65536);
+    return F;
+}
+void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
+                         const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
+                         int* d_failed, void* d_packed, hipStream_t s) {
+    const int ntiles = T.tiles_x * T.tiles_y;
+    const int tilepx = T.tile_w * T.tile_h;
+    FastArgs F = fast_args(P, lv, d_packed, s);
     F.limiterDiv = (float) (1 + std::sqrt((double) G.ditherMax));
     F.strideBytes = fast_stride_bytes(tilepx);
     F.failedCap = ntiles;
     F.failed = d_failed;
-    F.packed = (const uint4*) d_packed;
-    F.cont = F.packed + 2 * 65536;
-    hipLaunchKernelGGL(pack_lists_kernel, dim3(65536 / 256), dim3(256), 0, s, to_lists_fast(lv), (uint4*) d_packed, (uint4*) d_packed + 2 * 65536);
-    F.debug = 0;
 #ifdef NQ_FAST_KNOCKOUT
     if (const char* e = std::getenv("NQ_FAST_DEBUG")) F.debug = std::atoi(e);
 #endif
@@ -656,5 +763,26 @@ void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileG
                        seed, d_index, d_argb);
 }
 
+// the lookups alone (nq_nearest_index, nq_closest_tuple, LOOKUP_ONLY) through the same device functions
+bool fast_lookup_eligible(const DevParams& P, const ListsView& lv) {
+    return P.kind == 1 && P.K > 32 && P.K <= 256 && !P.hasSemi && !P.rewriteA0 && lv.closest && lv.nearest && P.ratio >= 0;
+}
+static inline int fast_grid(int64_t n) { int64_t g = (n + 255) / 256; return (int) (g < 1 ? 1 : g > 256 * 16 ? 256 * 16 : g); }
+void launch_fast_nearest_index(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_colors, int64_t M,
+                               short* d_out, hipStream_t s) {
+    const FastArgs F = fast_args(P, lv, d_packed, s);
+    hipLaunchKernelGGL(fast_nearest_index_kernel, dim3(fast_grid(M)), dim3(256), 0, s, P, to_lists_fast(lv), F, d_palette, d_colors, (long long) M, d_out);
+}
+void launch_fast_closest_tuple(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_colors, int64_t M,
+                               int* d_out4, hipStream_t s) {
+    const FastArgs F = fast_args(P, lv, d_packed, s);
+    hipLaunchKernelGGL(fast_closest_tuple_kernel, dim3(fast_grid(M)), dim3(256), 0, s, P, to_lists_fast(lv), F, d_palette, d_colors, (long long) M, d_out4);
+}
+void launch_fast_lookup_only(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_pixels, int64_t N,
+                             unsigned short* d_index, int* d_argb, hipStream_t s) {
+    const FastArgs F = fast_args(P, lv, d_packed, s);
+    hipLaunchKernelGGL(fast_lookup_only_kernel, dim3(fast_grid(N)), dim3(256), 0, s, P, to_lists_fast(lv), F, d_palette, d_pixels, (long long) N,
+                       d_index, d_argb);
+}
 
 } // namespace nq

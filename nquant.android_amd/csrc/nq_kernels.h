@@ -75,6 +75,13 @@ bool gilbert_fast_eligible(const DevParams& P, const GilbertConsts& G, const Til
 void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
                          const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
                          int* d_failed /* int[1 + tiles] */, void* d_packed /* 65536 x 64 bytes */, hipStream_t s);
+bool fast_lookup_eligible(const DevParams& P, const ListsView& lv);
+void launch_fast_nearest_index(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_colors, int64_t M,
+                               short* d_out, hipStream_t s);
+void launch_fast_closest_tuple(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_colors, int64_t M,
+                               int* d_out4, hipStream_t s);
+void launch_fast_lookup_only(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_pixels, int64_t N,
+                             unsigned short* d_index, int* d_argb, hipStream_t s);
 // BlueNoise.dither post-pass (NQ/BlueNoise.java:207-222); in-place on d_index, writes d_argb
 void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,
                       float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,

@@ -373,6 +373,7 @@ struct nqo_quantizer {
     int64_t seed;            /* the injected seed (per-tile / per-pixel streams of the tiled restatement derive from it) */
     /* bookkeeping (not in the reference) */
     int no_cache;            /* cache-miss semantics for the tiled restatement / pure lookups */
+    int saliencies_partial;  /* the saliency map covers a tile-row range only (nqo_dither_tile_rows): dropped after the pass */
     int64_t frozen_distinct; /* >=0: value used in place of pixelMap.size() by the tiled BlueNoise weight */
     int texicab, quan_rt, maxbins, nMaxColors, paletteLength;
     int64_t distinct_after_hist;
@@ -1372,11 +1373,11 @@ static void gilbert_run(nqo_quantizer* q, ditherable* dth, const int32_t* palett
 
 /* NQ/BlueNoise.java:207-222 (qIndex in: indices from the gilbert pass; out: final index + ARGB) */
 static void bluenoise_dither(nqo_quantizer* q, ditherable* dth, const int32_t* palette, int K, int32_t* qIndex,
-                             int32_t* out_argb, float weight, int per_pixel_rng) {
+                             int32_t* out_argb, float weight, int per_pixel_rng, int y_lo, int y_hi) {
     const float strength = 1 / 3.0f;
     int64_t px_rng;
     int64_t* save_rng = dth->rng;
-    for (int y = 0; y < q->height; ++y) {
+    for (int y = y_lo; y < y_hi; ++y) {
         for (int x = 0; x < q->width; ++x) {
             const int bidx = x + y * q->width;
             int32_t pixel = q->pixels[bidx];
@@ -1394,22 +1395,33 @@ static void bluenoise_dither(nqo_quantizer* q, ditherable* dth, const int32_t* p
     dth->rng = save_rng;
 }
 
+/* row_first / row_count (tiled mode only; row_count < 0 = all): restrict the pass to that range of TILE ROWS -- tiles are independent
+ * chains with their own Random(mix64(seed + tileIndex)), so any subset equals the same tiles of the whole-image run; pixels outside
+ * the range come back as index 0.  Lets the tests check a full-size image (BASELINE cfg 3-5) on a sample of its tile rows. */
 static int dither_impl(nqo_quantizer* q, const int32_t* palette, int K, int dither, int tile_w, int tile_h,
-                       int32_t* out_argb, int32_t* out_index) {
+                       int row_first, int row_count, int32_t* out_argb, int32_t* out_index) {
     const size_t N = (size_t) q->width * q->height;
     const int tiled = tile_w > 0 && tile_h > 0;
+    int y_lo = 0, y_hi = q->height;
+    if (tiled && row_count >= 0) {
+        y_lo = row_first * tile_h; y_hi = (row_first + row_count) * tile_h;
+        if (y_lo > q->height) y_lo = q->height;
+        if (y_hi > q->height) y_hi = q->height;
+    }
     ditherable dth = {q, dither, &q->rng};
     double t0 = now_s();
+    const double weight_in = q->weight;
     if (q->hasSemiTransparency) q->weight *= -1;          /* RGB :396-397, LAB :496-497 */
     if (q->kind == 1) {
         /* LAB :499-508 */
         if (dither && q->saliencies == NULL && (K <= 256 || q->weight > .99)) {
             q->saliencies = calloc(N ? N : 1, sizeof(float));
             float saliencyBase = .1f;
-            for (size_t i = 0; i < N; ++i) {
+            for (size_t i = (size_t) y_lo * q->width; i < (size_t) y_hi * q->width; ++i) {
                 Lab lab1 = getLab(q, q->pixels[i]);
                 q->saliencies[i] = saliencyBase + (1 - saliencyBase) * lab1.L / 100.0f * lab1.alpha / 255.0f;
             }
+            if (tiled && row_count >= 0) q->saliencies_partial = 1;
         }
     }
     const float* sal = q->kind == 1 ? q->saliencies : NULL;
@@ -1422,6 +1434,7 @@ static int dither_impl(nqo_quantizer* q, const int32_t* palette, int K, int dith
         int tix = 0;
         for (int ty = 0; ty < q->height; ty += tile_h)
             for (int tx = 0; tx < q->width; tx += tile_w, ++tix) {
+                if (ty < y_lo || ty >= y_hi) continue;
                 int tw = q->width - tx < tile_w ? q->width - tx : tile_w;
                 int th = q->height - ty < tile_h ? q->height - ty : tile_h;
                 /* per-tile stream: java.util.Random(mix64(seed + tileIndex)) */
@@ -1440,7 +1453,8 @@ static int dither_impl(nqo_quantizer* q, const int32_t* palette, int K, int dith
             double delta = sqr(K) / (double) sz;
             bw = delta > 0.023 ? 1.0f : (float) (37.013 * delta + 0.906);
         }
-        bluenoise_dither(q, &dth, palette, K, qIndex, out_argb, bw, tiled);
+        for (size_t i = 0; i < N; ++i) out_argb[i] = palette[qIndex[i]];
+        bluenoise_dither(q, &dth, palette, K, qIndex, out_argb, bw, tiled, y_lo, y_hi);
     } else {
         for (size_t i = 0; i < N; ++i) out_argb[i] = palette[qIndex[i]];
     }
@@ -1449,17 +1463,24 @@ static int dither_impl(nqo_quantizer* q, const int32_t* palette, int K, int dith
     q->no_cache = 0;
     imap_clear(&q->closestMap); imap_clear(&q->nearestMap);
     if (q->kind == 1) imap_clear(&q->pixelMap);
+    if (q->saliencies_partial) { free(q->saliencies); q->saliencies = NULL; q->saliencies_partial = 0; }
+    if (tiled) q->weight = weight_in;      /* the tiled restatement may be called repeatedly on one object (the GPU handle keeps its weight too) */
     q->t_stage[5] += now_s() - t0;
     return 0;
 }
 
 int nqo_dither(nqo_quantizer* q, const int32_t* palette, int K, int dither, int32_t* out_argb, int32_t* out_index) {
-    return dither_impl(q, palette, K, dither, 0, 0, out_argb, out_index);
+    return dither_impl(q, palette, K, dither, 0, 0, 0, -1, out_argb, out_index);
 }
 int nqo_dither_tiled(nqo_quantizer* q, const int32_t* palette, int K, int dither, int tile_w, int tile_h,
                      int32_t* out_argb, int32_t* out_index) {
     q->frozen_distinct = q->distinct_after_hist;
-    return dither_impl(q, palette, K, dither, tile_w, tile_h, out_argb, out_index);
+    return dither_impl(q, palette, K, dither, tile_w, tile_h, 0, -1, out_argb, out_index);
+}
+int nqo_dither_tile_rows(nqo_quantizer* q, const int32_t* palette, int K, int dither, int tile_w, int tile_h, int row_first, int row_count,
+                         int32_t* out_argb, int32_t* out_index) {
+    q->frozen_distinct = q->distinct_after_hist;
+    return dither_impl(q, palette, K, dither, tile_w, tile_h, row_first, row_count, out_argb, out_index);
 }
 
 /* NQ/PnnQuantizer.java:410-436 */

@@ -72,6 +72,13 @@ int  nqo_dither(nqo_quantizer* q, const int32_t* palette, int K, int dither,
 int  nqo_dither_tiled(nqo_quantizer* q, const int32_t* palette, int K, int dither, int tile_w, int tile_h,
                       int32_t* out_argb, int32_t* out_index);
 
+/* The same, restricted to the tile rows [row_first, row_first + row_count): tiles are independent, so the result equals those
+ * rows of nqo_dither_tiled; pixels outside come back as index 0 / palette[0].  For full-size images checked on a sample of rows. */
+int  nqo_dither_tile_rows(nqo_quantizer* q, const int32_t* palette, int K, int dither, int tile_w, int tile_h,
+                          int row_first, int row_count, int32_t* out_argb, int32_t* out_index);
+/* diagnostics: event counters of the per-pixel pass (tools/oracle_event_rates.py) */
+void nqo_debug_counters(int64_t* out16, int reset);
+
 /* Pure lookups with cache-miss semantics (memo cleared before every colour). */
 void nqo_nearest_index(nqo_quantizer* q, const int32_t* palette, int K, const int32_t* colors, int64_t M,
                        int16_t* out_index);

@@ -49,6 +49,7 @@ def lib():
     L.nqo_pnnquan.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.nqo_dither.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.nqo_dither_tiled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.nqo_dither_tile_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.nqo_nearest_index.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     L.nqo_closest_tuple.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     L.nqo_get_color_index.restype = C.c_int32
@@ -153,6 +154,16 @@ class OracleQuantizer:
         else:
             self._L.nqo_dither_tiled(self._h, palette.ctypes.data, len(palette), int(dither), int(tile[0]), int(tile[1]),
                                      out.ctypes.data, idx.ctypes.data)
+        return out.reshape(self.height, self.width), idx.reshape(self.height, self.width)
+
+    def dither_tile_rows(self, palette, dither, tile, row_first, row_count):
+        """Tiled dither of the tile rows [row_first, row_first + row_count) only (tiles are independent chains)."""
+        palette = _i32(palette)
+        n = self.width * self.height
+        out = np.zeros(n, np.int32)
+        idx = np.zeros(n, np.int32)
+        self._L.nqo_dither_tile_rows(self._h, palette.ctypes.data, len(palette), int(dither), int(tile[0]), int(tile[1]),
+                                     int(row_first), int(row_count), out.ctypes.data, idx.ctypes.data)
         return out.reshape(self.height, self.width), idx.reshape(self.height, self.width)
 
     def nearest_index(self, palette, colors):
