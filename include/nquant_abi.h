@@ -83,6 +83,13 @@ int nq_set_stream(nq_handle* h, void* hip_stream);
 /* Tile of the PARALLEL_TILED decomposition; <= 0 (default) = automatic: the largest of 16x16, 8x8, 4x4 that gives the GPU
  * at least 131072 independent chains. */
 int nq_set_tile(nq_handle* h, int tile_w, int tile_h);
+/* One image tiled over GPUs: this handle's following nq_dither[_device] calls treat their pixel buffer as the rows
+ * [y0, y0 + height) of an image of image_height rows -- tile random streams, the blue-noise phase and the position-dependent
+ * gates (`bidx & 4095`, `pos % 2`) are those of the whole image, so the bands of an image equal the same rows of the single-GPU
+ * PARALLEL_TILED result.  y0 (and every band's row count but the last) must be a multiple of the tile height; the automatic tile
+ * follows the whole image.  (0, 0) = a whole image again.  Not for REFERENCE_SEQUENTIAL. */
+int nq_set_band(nq_handle* h, int y0, int image_height);
+
 /* Tuning switches that never change results.  NQ_OPT_CELL_LISTS (default 1): scan only the per-colour-cell candidate
  * lists in nearest/closestColorIndex (exact, csrc/nq_lists.inc); 0 = scan the whole palette like the reference. */
 #define NQ_OPT_CELL_LISTS 1
@@ -190,6 +197,15 @@ int nq_palette_from_histograms_device(nq_handle* h, const double* d_hists, int n
 int nq_band_distinct_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, int cap, int64_t* out_count,
                             uint32_t* out_colors);
 int nq_set_distinct(nq_handle* h, int64_t count, const uint32_t* colors);
+
+/* Image-wide distinct-colour count of a banded LAB run (it sets the BlueNoise weight of convert(n, false),
+ * NQ/PnnLABQuantizer.java:511-515, and lives in nq_params.distinctColors): every rank marks the opaque colours of its band in
+ * d_presence (2^24 bytes, one per RGB value; the caller zeroes it once and may pass the same table for several bands) and gets
+ * the band's non-opaque colours (after the alpha <= 15 substitution; needs nq_set_scan first) as a list -- *out_other_count = -1
+ * when there are more than cap_other (<= 131072).  The caller combines the tables by byte-wise MAX (an all-reduce), counts their
+ * non-zero bytes, adds the size of the union of the lists and stores the sum with nq_set_params. */
+int nq_band_color_presence_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, uint8_t* d_presence, int cap_other,
+                                  int64_t* out_other_count, uint32_t* out_other);
 
 /* Wall-clock of the stages of the last nq_convert*_ call on this handle, milliseconds, measured with HIP
  * events on the handle's stream: {prescan, histogram, nn_init, merge, palette_fill, dither, bluenoise, total}. */

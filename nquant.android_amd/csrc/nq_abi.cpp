@@ -162,6 +162,7 @@ struct nq_handle {
     DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..19] merge stats, [20..21] distinct-colour result
     DevBuf<int> live3;                // merge loop: two live lists + position index
     int use_lists = 1;
+    int band_y0 = 0, band_image_h = 0; // nq_set_band: this handle dithers a row band of a larger image (0, 0 = a whole image)
     int use_fast_dither = 1;          // NQ_OPT_FAST_DITHER: the specialised dither kernel where the configuration allows it
     int last_dither_fast = 0;         // diagnostics: 1 if the last dither pass ran gilbert_fast_kernel
     int last_dither_failed_tiles = 0; // ... and how many tiles it handed back to the generic kernel (read lazily)
@@ -645,6 +646,10 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     TileGeom T;
     std::memset(&T, 0, sizeof T);
     T.width = width; T.height = height;
+    const bool banded = h->band_image_h > 0;
+    if (banded && (sequential || h->band_y0 + height > h->band_image_h))
+        NQ_FAIL(h, NQ_ERR_INVALID, "nq_set_band: the band [%d, %d) does not fit the image height %d (or REFERENCE_SEQUENTIAL mode)", h->band_y0, h->band_y0 + height, h->band_image_h);
+    const int rule_h = banded ? h->band_image_h : height;          // the automatic tile follows the WHOLE image
     if (sequential) { T.tile_w = width; T.tile_h = height; }
     else if (h->tile_w > 0 && h->tile_h > 0) { T.tile_w = std::min(h->tile_w, width); T.tile_h = std::min(h->tile_h, height); }
     else {
@@ -652,10 +657,18 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         // the tile size does not change the measured dither quality, it only sets how many chains run in parallel
         int tsz = 4;
         for (int cand : {16, 8}) {
-            const int64_t tiles = (int64_t) ((width + cand - 1) / cand) * ((height + cand - 1) / cand);
+            const int64_t tiles = (int64_t) ((width + cand - 1) / cand) * ((rule_h + cand - 1) / cand);
             if (tiles >= 131072) { tsz = cand; break; }
         }
-        T.tile_w = std::min(tsz, width); T.tile_h = std::min(tsz, height);
+        T.tile_w = std::min(tsz, width); T.tile_h = std::min(tsz, rule_h);
+    }
+    if (banded) {
+        T.tile_h = std::min(T.tile_h, h->band_image_h);
+        if (h->band_y0 % T.tile_h != 0 || (h->band_y0 + height != h->band_image_h && height % T.tile_h != 0))
+            NQ_FAIL(h, NQ_ERR_INVALID, "nq_set_band: band origin %d / rows %d must be multiples of the tile height %d", h->band_y0, height, T.tile_h);
+        T.y_origin = h->band_y0;
+        T.tile_base = (h->band_y0 / T.tile_h) * ((width + T.tile_w - 1) / T.tile_w);
+        T.tile_h = std::min(T.tile_h, height);
     }
     T.tiles_x = (width + T.tile_w - 1) / T.tile_w; T.tiles_y = (height + T.tile_h - 1) / T.tile_h;
     const int rw = width - (T.tiles_x - 1) * T.tile_w, rh = height - (T.tiles_y - 1) * T.tile_h;
@@ -721,7 +734,7 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         blueWeight = delta > 0.023 ? 1.0f : (float) (37.013 * delta + 0.906);
     }
     if (post)
-        launch_bluenoise(P, h->d_palette.p, lv, (const int*) d_argb, width, height, blueWeight, (long long) seed, sequential ? 1 : 0,
+        launch_bluenoise(P, h->d_palette.p, lv, (const int*) d_argb, width, height, T.y_origin, blueWeight, (long long) seed, sequential ? 1 : 0,
                          h->d_bincache.p, h->d_scalars.p, d_out_index, (int*) d_out_argb, h->stream);
     rec(h, 7);
     NQ_HIP(h, hipGetLastError());
@@ -786,6 +799,13 @@ int nq_set_tile(nq_handle* h, int tile_w, int tile_h) {
     if (!h) return NQ_ERR_INVALID;
     if (tile_w <= 0 || tile_h <= 0) { tile_w = 0; tile_h = 0; }
     h->tile_w = tile_w; h->tile_h = tile_h;
+    return NQ_OK;
+}
+int nq_set_band(nq_handle* h, int y0, int image_height) {
+    if (!h) return NQ_ERR_INVALID;
+    if (y0 < 0 || image_height < 0 || (image_height == 0 && y0 != 0) || (image_height > 0 && y0 >= image_height))
+        NQ_FAIL(h, NQ_ERR_INVALID, "nq_set_band: bad origin %d / image height %d", y0, image_height);
+    h->band_y0 = y0; h->band_image_h = image_height;
     return NQ_OK;
 }
 int nq_get_list_counts(nq_handle* h, uint8_t* closest_counts, uint8_t* nearest_counts) {
@@ -1142,6 +1162,31 @@ int nq_band_distinct_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixe
     rc = distinct_colors(h, d_argb, n_pixels, cap, out_count, &cols);
     if (rc) return rc;
     if (*out_count <= cap) std::memcpy(out_colors, cols.data(), cols.size() * sizeof(int32_t));
+    return NQ_OK;
+}
+
+int nq_band_color_presence_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, uint8_t* d_presence, int cap_other,
+                                  int64_t* out_other_count, uint32_t* out_other) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!d_argb || n_pixels <= 0 || !d_presence || cap_other < 1 || !out_other_count || !out_other) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    const unsigned slots = 1u << 18;
+    if ((unsigned) cap_other > slots / 2) NQ_FAIL(h, NQ_ERR_INVALID, "cap_other above %u", slots / 2);
+    NQ_HIP(h, h->sc->dk_a.reserve((size_t) slots + 2));
+    unsigned* d_set = h->sc->dk_a.p;
+    unsigned* d_cnt = d_set + slots;
+    launch_color_presence((const int*) d_argb, n_pixels, h->params.transparentColor, d_presence, d_set, slots, d_cnt, h->stream);
+    NQ_HIP(h, hipGetLastError());
+    unsigned cnt[2] = {0, 0};
+    NQ_HIP(h, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (cnt[1] || cnt[0] > (unsigned) cap_other) { *out_other_count = -1; return NQ_OK; }      // too many non-opaque colours: caller decides
+    std::vector<unsigned> set(slots);
+    NQ_HIP(h, hipMemcpy(set.data(), d_set, (size_t) slots * sizeof(unsigned), hipMemcpyDeviceToHost));
+    int64_t k = 0;
+    for (unsigned v : set) if (v != 0xFFFFFFFFu && k < cap_other) out_other[k++] = v;
+    *out_other_count = k;
     return NQ_OK;
 }
 

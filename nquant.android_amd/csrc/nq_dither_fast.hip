@@ -417,7 +417,8 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
     const unsigned* __restrict__ path = S.path + shape * tilepx;
     unsigned char* stage = S.stage + (size_t) tid * F.strideBytes;        // (wave w, lane l) -> row 64 w + l
     const int width = T.width;
-    long long rng = jr_seed((long long) mix64((unsigned long long) seed + (unsigned long long) tile));
+    long long rng = jr_seed((long long) mix64((unsigned long long) seed + (unsigned long long) (T.tile_base + tile)));
+    const int gofs = T.y_origin * width;        // band-local pixel index -> pixel index in the whole image (TileGeom::y_origin)
     const bool branchA = G.hasSaliencies && G.dither;                      // (!hasAlphaW: no semi-transparency here)
     const bool hasSal = G.hasSaliencies != 0;
     FastLookup X;
@@ -450,7 +451,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
             const int pixel = pixel_next;
             const float sal = sal_next;
             const int dxx = (int) (d_next & 0xFFFFu), dyy = (int) (d_next >> 16);
-            const int xx = x0 + dxx, yy = y0 + dyy, pos = dyy * T.tile_w + dxx;
+            const int xx = x0 + dxx, yy = y0 + dyy + T.y_origin, pos = dyy * T.tile_w + dxx;      // (xx, yy): position in the whole image
             if (s + 1 < steps) {
                 d_next = path[s + 1];
                 bidx_next = (x0 + (int) (d_next & 0xFFFFu)) + (y0 + (int) (d_next >> 16)) * width;
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
             e[1] = (float) (g_pix - c_green(cq));
             e[2] = (float) (b_pix - c_blue(cq));
             e[3] = (float) (a_pix - c_alpha(cq));
-            const bool diffuse = S.blue[bidx & 4095] > G.thresold;
+            const bool diffuse = S.blue[(bidx + gofs) & 4095] > G.thresold;
             {
                 float ea = e[0], eb = e[1], ec = e[2];
 #pragma unroll 1

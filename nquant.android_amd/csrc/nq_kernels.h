@@ -39,6 +39,11 @@ struct TileGeom {
     const uint32_t* path[4];
     int path_len[4];
     int shape_w[4], shape_h[4];
+    // a row band of a larger image (one image tiled over GPUs): the band starts at image row y_origin (a multiple of
+    // tile_h) and its first tile is tile number tile_base of the whole image.  Pixel buffers are band-local; the tile's random
+    // stream, the blue-noise phase (x, y), the `bidx & 4095` gates and the pixel position handed to the lookups are those of the
+    // whole image, so that the bands of an image equal the same rows of the single-GPU result.  0 / 0 for a whole image.
+    int y_origin, tile_base;
 };
 
 void upload_tables(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s);        // nq_kernels.hip's copy
@@ -84,6 +89,7 @@ void launch_fast_lookup_only(const DevParams& P, const ListsView& lv, const int*
                              unsigned short* d_index, int* d_argb, hipStream_t s);
 // BlueNoise.dither post-pass (NQ/BlueNoise.java:207-222); in-place on d_index, writes d_argb
 void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,
+                      int y_origin /* band start row in the whole image, 0 otherwise */,
                       float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,
                       unsigned short* d_index, int* d_argb, hipStream_t s);
 
@@ -113,6 +119,9 @@ size_t sort_temp_bytes(int64_t n);
 size_t sort32_temp_bytes(int64_t n, bool pairs);
 void launch_distinct(const int* d_pixels, int64_t n, int transparentColor, unsigned* keys_a, unsigned* keys_b, unsigned* idx_a,
                      unsigned* idx_b, void* tmp, size_t tmp_bytes, unsigned long long* d_out, void* d_heads, unsigned cap, hipStream_t s);
+// colours present in a band: opaque ones mark d_bytes[rgb] (2^24 bytes, NOT cleared here: bands accumulate), the others enter the set
+void launch_color_presence(const int* d_pixels, int64_t n, int transparentColor, unsigned char* d_bytes, unsigned* d_set, unsigned slots,
+                           unsigned* d_counters, hipStream_t s);
 void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s);
 void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams& hp, const SortWorkspace& ws,
                       double* d_hist, hipStream_t s);

@@ -110,7 +110,7 @@ void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& 
 }
 
 void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,
-                      float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,
+                      int y_origin, float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,
                       unsigned short* d_index, int* d_argb, hipStream_t s) {
     const size_t smem = palette_smem_bytes(P.kind, P.K);
     if (sequential)
@@ -118,7 +118,7 @@ void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView&
                            d_binCache, d_rng_state, d_index, d_argb);
     else
         hipLaunchKernelGGL(bluenoise_kernel, dim3(grid_for((int64_t) width * height, 256, 256 * 16)), dim3(256), palette_tables_smem_bytes(P.kind, P.K), s,
-                           P, d_palette, to_lists(lv), d_pixels, width, height, weight, seed, d_index, d_argb);
+                           P, d_palette, to_lists(lv), d_pixels, width, height, y_origin, weight, seed, d_index, d_argb);
 }
 
 // ---- palette build launchers ----
@@ -153,6 +153,13 @@ void launch_distinct(const int* d_pixels, int64_t n, int transparentColor, unsig
                        d_out, (uint2*) d_heads, cap);
 }
 
+void launch_color_presence(const int* d_pixels, int64_t n, int transparentColor, unsigned char* d_bytes, unsigned* d_set, unsigned slots,
+                           unsigned* d_counters, hipStream_t s) {
+    (void) hipMemsetAsync(d_set, 0xFF, (size_t) slots * sizeof(unsigned), s);
+    (void) hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned), s);
+    hipLaunchKernelGGL(color_presence_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, transparentColor,
+                       d_bytes, d_set, slots, d_counters);
+}
 void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s) {
     (void) hipMemsetAsync(d_scan3, 0xFF, 2 * sizeof(long long), s);      // {-1, -1}
     (void) hipMemsetAsync(d_scan3 + 2, 0, sizeof(long long), s);

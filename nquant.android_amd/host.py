@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "nq_set_params", "nq_convert", "nq_convert_device", "nq_convert_batch_device", "nq_convert_batch", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
     "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_band_distinct_device", "nq_set_distinct", "nq_get_stage_ms", "nq_get_merge_stats",
-    "nq_get_dither_path",
+    "nq_get_dither_path", "nq_set_band", "nq_band_color_presence_device",
 ]
 OPT_CELL_LISTS, OPT_FAST_DITHER = 1, 2
 
@@ -118,6 +118,8 @@ def load_library():
     L.nq_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nq_get_merge_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.nq_get_dither_path.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.nq_set_band.argtypes = [vp, i32, i32]
+    L.nq_band_color_presence_device.argtypes = [vp, vp, i64, vp, i32, C.POINTER(C.c_int64), vp]
     _LIB = L
     return L
 
@@ -184,6 +186,10 @@ class PnnQuantizer:
 
     def set_tile(self, tile_w, tile_h):
         self._check(self._L.nq_set_tile(self._h, tile_w, tile_h))
+
+    def set_band(self, y0, image_height):
+        """The following dither calls treat their buffer as rows [y0, ...) of an image of image_height rows (0, 0 = whole image)."""
+        self._check(self._L.nq_set_band(self._h, int(y0), int(image_height)))
 
     def list_counts(self):
         c = np.zeros(65536, np.uint8)

@@ -19,11 +19,19 @@ def shard_frames(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
-def band_bounds(height, rank, world):
-    """Row band [y0, y1) of `rank`: equal bands, the remainder rows go to the first bands."""
-    base, rem = divmod(height, world)
-    y0 = rank * base + min(rank, rem)
-    return y0, y0 + base + (1 if rank < rem else 0)
+BAND_ALIGN = 64      # rows: a multiple of every tile height (16, 8, 4) and of the 64-row blue-noise period
+
+
+def band_bounds(height, rank, world, align=BAND_ALIGN):
+    """Row band [y0, y1) of `rank`: the image is cut at multiples of `align` rows (a band must start on a tile boundary for its
+    dither to equal the same rows of the single-GPU result); the blocks are dealt out evenly, the first bands take the remainder,
+    the last block may be short.  With fewer blocks than ranks the last ranks get an EMPTY band (y0 == y1): they still take part in
+    every collective of convert_banded."""
+    blocks = (height + align - 1) // align
+    base, rem = divmod(blocks, world)
+    b0 = rank * base + min(rank, rem)
+    b1 = b0 + base + (1 if rank < rem else 0)
+    return min(b0 * align, height), min(b1 * align, height)
 
 
 def reduce_scan(scan3, group=None):
@@ -96,23 +104,62 @@ def max_over_ranks(seconds, device="cpu", group=None):
     return float(t.item())
 
 
-def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_argb, d_out_index=None, group=None):
+def image_distinct_count(q, d_band, n, device, group=None, cap_other=65536):
+    """Distinct colours of the WHOLE image (as the histogram sees them) from the bands of all ranks: byte-wise MAX all-reduce of
+    the 2^24-byte opaque-colour tables (16 MB) + union of the short non-opaque lists.  Returns None when some band has more than
+    cap_other non-opaque colours (the caller then keeps the band-local count: stated deviation for such images)."""
+    import ctypes as C
+    presence = torch.zeros(1 << 24, dtype=torch.uint8, device=device)
+    other = np.zeros(cap_other, np.uint32)
+    cnt = C.c_int64(0)
+    if n > 0:
+        q._check(q._L.nq_band_color_presence_device(q._h, C.c_void_p(d_band.data_ptr()), n, C.c_void_p(presence.data_ptr()), cap_other,
+                                                    C.byref(cnt), other.ctypes.data))
+    backend = dist.get_backend(group)
+    red = presence if (backend == "nccl" or not presence.is_cuda) else presence.cpu()
+    dist.all_reduce(red, op=dist.ReduceOp.MAX, group=group)
+    opaque = int(torch.count_nonzero(red))
+    t = torch.full((cap_other + 1,), -1, dtype=torch.int64)
+    k = int(cnt.value)
+    t[0] = k
+    if k > 0:
+        t[1:1 + k] = torch.from_numpy(other[:k].astype(np.int64))
+    allv = _gather_small(t, group)
+    if bool((allv[:, 0] < 0).any()):
+        return None
+    others = set()
+    for r in range(allv.shape[0]):
+        others.update(allv[r, 1:1 + int(allv[r, 0])].tolist())
+    return opaque + len(others)
+
+
+def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_argb, d_out_index=None, group=None, image_height=None):
     """One image tiled over the ranks of `group` (GPU only).  q: a PnnQuantizer/PnnLABQuantizer of this rank; d_band: this
-    rank's rows as a CUDA int32 tensor.  Returns the (shared) palette."""
+    rank's rows [y0, y0 + band_rows) as a CUDA int32 tensor (band_rows may be 0: the rank then only takes part in the collectives);
+    image_height: rows of the whole image (default: the sum of the bands' rows).  Bands must start on multiples of the tile height
+    (band_bounds cuts at multiples of 64).  Returns the (shared) palette; the band's pixels equal rows [y0, y0 + band_rows) of the
+    single-GPU PARALLEL_TILED convert of the whole image given the same palette."""
     import ctypes as C
     L = q._L
     n = width * band_rows
-    scan3 = torch.empty(3, dtype=torch.int64, device=d_band.device)
-    q._check(L.nq_band_scan_device(q._h, C.c_void_p(d_band.data_ptr()), n, y0 * width, nMaxColors, C.c_void_p(scan3.data_ptr())))
+    dev = d_out_argb.device if band_rows == 0 else d_band.device
+    if image_height is None:
+        t = torch.tensor([band_rows], dtype=torch.int64)
+        image_height = int(_gather_small(t, group).sum())
+    scan3 = torch.tensor([-1, -1, 0], dtype=torch.int64, device=dev)
+    if n > 0:
+        q._check(L.nq_band_scan_device(q._h, C.c_void_p(d_band.data_ptr()), n, y0 * width, nMaxColors, C.c_void_p(scan3.data_ptr())))
     idx, color, semi = reduce_scan(scan3, group)
     q._check(L.nq_set_scan(q._h, nMaxColors, idx, C.c_uint32(color & 0xFFFFFFFF), semi))
-    hist = torch.empty(HIST_BINS * HIST_STRIDE, dtype=torch.float64, device=d_band.device)
-    q._check(L.nq_band_histogram_device(q._h, C.c_void_p(d_band.data_ptr()), n, C.c_void_p(hist.data_ptr())))
+    hist = torch.zeros(HIST_BINS * HIST_STRIDE, dtype=torch.float64, device=dev)
+    if n > 0:
+        q._check(L.nq_band_histogram_device(q._h, C.c_void_p(d_band.data_ptr()), n, C.c_void_p(hist.data_ptr())))
     hists = gather_histograms(hist, group)
     if q.KIND == 1 and int((hists.view(hists.shape[0], HIST_BINS, HIST_STRIDE)[:, :, 0].sum(0) > 0).sum()) <= nMaxColors:
         # NQ/PnnLABQuantizer.java:193-206: with so few occupied bins the image may hold <= nMaxColors distinct colours, and the
         # reference then returns them as they are -- every rank takes this branch together (the gathered histograms are identical)
-        merged = merge_distinct(band_distinct(q, d_band, n, nMaxColors), nMaxColors, group)
+        mine = band_distinct(q, d_band, n, nMaxColors) if n > 0 else []
+        merged = merge_distinct(mine, nMaxColors, group)
         cols = np.asarray(merged if merged is not None else [], np.int32)
         q._check(L.nq_set_distinct(q._h, len(cols) if merged is not None else -1, cols.ctypes.data))
     pal = np.zeros(max(nMaxColors, 2), np.int32)
@@ -120,6 +167,18 @@ def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_ar
     q._check(L.nq_palette_from_histograms_device(q._h, C.c_void_p(hists.data_ptr()), hists.shape[0], nMaxColors,
                                                  pal.ctypes.data, C.byref(K)))
     pal = pal[:K.value].copy()
-    q.width, q.height = width, band_rows
-    q.dither_device(d_band.data_ptr(), pal, dither, d_out_argb.data_ptr(), d_out_index.data_ptr() if d_out_index is not None else 0)
+    if q.KIND == 1 and not dither and K.value > 32:
+        # BlueNoise weight of convert(n, false): delta = K^2 / pixelMap.size() over the WHOLE image (NQ/PnnLABQuantizer.java:511-515)
+        total = image_distinct_count(q, d_band, n, dev, group)
+        if total is not None:
+            p = q.params
+            p.distinctColors = total
+            q.set_params(p)
+    if band_rows > 0:
+        q.width, q.height = width, band_rows
+        q.set_band(y0, image_height)
+        try:
+            q.dither_device(d_band.data_ptr(), pal, dither, d_out_argb.data_ptr(), d_out_index.data_ptr() if d_out_index is not None else 0)
+        finally:
+            q.set_band(0, 0)
     return pal

@@ -373,6 +373,8 @@ struct nqo_quantizer {
     int64_t seed;            /* the injected seed (per-tile / per-pixel streams of the tiled restatement derive from it) */
     /* bookkeeping (not in the reference) */
     int no_cache;            /* cache-miss semantics for the tiled restatement / pure lookups */
+    int n_bands;             /* > 1: the LAB histogram sums restart at every band (nqo_set_bands) and the partials are added in band order */
+    int band_row[65];        /* first row of band b; band_row[n_bands] = height */
     int saliencies_partial;  /* the saliency map covers a tile-row range only (nqo_dither_tile_rows): dropped after the pass */
     int64_t frozen_distinct; /* >=0: value used in place of pixelMap.size() by the tiled BlueNoise weight */
     int texicab, quan_rt, maxbins, nMaxColors, paletteLength;
@@ -405,6 +407,12 @@ void nqo_destroy(nqo_quantizer* q) {
     free(q->pixels); free(q->saliencies);
     imap_free(&q->closestMap); imap_free(&q->nearestMap); imap_free(&q->pixelMap);
     free(q);
+}
+/* multi-GPU band split: rows [row_start[b], row_start[b+1]) form band b; n_bands <= 1 switches it off */
+void nqo_set_bands(nqo_quantizer* q, int n_bands, const int32_t* row_start) {
+    q->n_bands = (n_bands > 1 && n_bands <= 64) ? n_bands : 0;
+    for (int b = 0; b < q->n_bands; ++b) q->band_row[b] = row_start[b];
+    if (q->n_bands) q->band_row[q->n_bands] = q->height;
 }
 void nqo_set_seed(nqo_quantizer* q, int64_t seed) { q->seed = seed; nqo_jrandom_seed(&q->rng, seed); }
 void nqo_get_params(const nqo_quantizer* q, nqo_params* o) {
@@ -671,19 +679,39 @@ static int pnnquan_lab(nqo_quantizer* q, int nMaxColors, int32_t* palette) {
     q->saliencies = nMaxColors >= 128 ? NULL : calloc(N ? N : 1, sizeof(float));
     float saliencyBase = .1f;
     double t0 = now_s();
-    /* :139-157 */
-    for (size_t p = 0; p < N; ++p) {
-        int32_t pixel = q->pixels[p];
-        if (c_alpha(pixel) <= q->alphaThreshold) pixel = q->m_transparentColor;
-        int index = nqo_get_color_index(pixel, q->hasSemiTransparency, nMaxColors < 64 || q->m_transparentPixelIndex >= 0);
-        Lab lab1 = getLab(q, pixel);
-        PnnbinLAB* tb = &bins[index];
-        tb->present = 1;
-        tb->ac += lab1.alpha; tb->Lc += lab1.L; tb->Ac += lab1.A; tb->Bc += lab1.B;
-        tb->cnt += 1.0f;
-        if (q->saliencies)
-            q->saliencies[p] = saliencyBase + (1 - saliencyBase) * lab1.L / 100.0f * lab1.alpha / 255.0f;
+    /* :139-157.  Banded restatement (n_bands > 1, the multi-GPU split of SURVEY 8e): the float sums of a bin restart at every band
+     * and the band partials are added in band order, all in float32 -- exactly what nq_palette_from_histograms_device does with the
+     * gathered per-band histograms; the count is exact and saturates at 2^24 like `cnt += 1.0f`.  n_bands <= 1: the reference. */
+    const int nb = q->n_bands > 1 ? q->n_bands : 1;
+    PnnbinLAB* part = nb > 1 ? calloc(65536 + 1, sizeof *part) : NULL;
+    double* exact_cnt = nb > 1 ? calloc(65536 + 1, sizeof(double)) : NULL;
+    for (int b = 0; b < nb; ++b) {
+        const size_t p_lo = nb > 1 ? (size_t) q->band_row[b] * q->width : 0, p_hi = nb > 1 ? (size_t) q->band_row[b + 1] * q->width : N;
+        PnnbinLAB* acc = nb > 1 ? part : bins;
+        if (nb > 1) memset(part, 0, (65536 + 1) * sizeof *part);
+        for (size_t p = p_lo; p < p_hi; ++p) {
+            int32_t pixel = q->pixels[p];
+            if (c_alpha(pixel) <= q->alphaThreshold) pixel = q->m_transparentColor;
+            int index = nqo_get_color_index(pixel, q->hasSemiTransparency, nMaxColors < 64 || q->m_transparentPixelIndex >= 0);
+            Lab lab1 = getLab(q, pixel);
+            PnnbinLAB* tb = &acc[index];
+            tb->present = 1;
+            tb->ac += lab1.alpha; tb->Lc += lab1.L; tb->Ac += lab1.A; tb->Bc += lab1.B;
+            tb->cnt += 1.0f;
+            if (nb > 1) exact_cnt[index] += 1.0;
+            if (q->saliencies)
+                q->saliencies[p] = saliencyBase + (1 - saliencyBase) * lab1.L / 100.0f * lab1.alpha / 255.0f;
+        }
+        if (nb > 1)
+            for (int i = 0; i < 65536; ++i) {
+                if (!part[i].present) continue;
+                PnnbinLAB* tb = &bins[i];
+                if (!tb->present) { tb->present = 1; tb->ac = part[i].ac; tb->Lc = part[i].Lc; tb->Ac = part[i].Ac; tb->Bc = part[i].Bc; }
+                else { tb->ac += part[i].ac; tb->Lc += part[i].Lc; tb->Ac += part[i].Ac; tb->Bc += part[i].Bc; }
+                tb->cnt = (float) (exact_cnt[i] > 16777216.0 ? 16777216.0 : exact_cnt[i]);
+            }
     }
+    free(part); free(exact_cnt);
     q->distinct_after_hist = (int64_t) q->pixelMap.n;
     /* :160-173 */
     int maxbins = 0;

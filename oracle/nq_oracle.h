@@ -48,6 +48,9 @@ typedef struct nqo_params {
 /* ---- object mirroring new PnnQuantizer(fname) / new PnnLABQuantizer(fname) (pixels handed in decoded) ---- */
 nqo_quantizer* nqo_create(int kind, const int32_t* argb, int width, int height);
 void nqo_destroy(nqo_quantizer* q);
+/* Banded restatement of the LAB histogram for the multi-GPU split: the float32 sums of a bin restart at the first row of
+ * every band (row_start[0] = 0 < row_start[1] < ... ) and the band partials are added in band order.  n_bands <= 1: reference order. */
+void nqo_set_bands(nqo_quantizer* q, int n_bands, const int32_t* row_start);
 void nqo_set_seed(nqo_quantizer* q, int64_t seed);      /* replaces the unseeded static Random (LAB :22) */
 void nqo_get_params(const nqo_quantizer* q, nqo_params* out);
 void nqo_set_params(nqo_quantizer* q, const nqo_params* in);  /* for function-level tests */

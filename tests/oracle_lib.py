@@ -42,6 +42,7 @@ def lib():
     L.nqo_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
     L.nqo_destroy.argtypes = [C.c_void_p]
     L.nqo_set_seed.argtypes = [C.c_void_p, C.c_int64]
+    L.nqo_set_bands.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.nqo_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.nqo_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.nqo_convert.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, p32]
@@ -113,6 +114,11 @@ class OracleQuantizer:
 
     def set_seed(self, seed):
         self._L.nqo_set_seed(self._h, seed)
+
+    def set_bands(self, row_starts):
+        """Banded restatement of the LAB histogram: float sums restart at these rows, partials added in band order."""
+        a = np.asarray(list(row_starts), np.int32)
+        self._L.nqo_set_bands(self._h, len(a), a.ctypes.data)
 
     @property
     def params(self):

@@ -49,7 +49,8 @@ def _worker(rank, world, port, tmp):
     assert parallel.shard_frames(7, rank, world) == list(range(rank, 7, world))
     H, W = 37, 24
     img = synth.with_alpha(synth.uniform_rgb(W, H, 9), 9)
-    y0, y1 = parallel.band_bounds(H, rank, world)
+    y0, y1 = parallel.band_bounds(H, rank, world, align=8)      # [0, 24) and [24, 37)
+    assert y1 > y0
     band = img[y0:y1]
     scan3 = torch.from_numpy(_numpy_band(band, y0 * W))
     idx, color, semi = parallel.reduce_scan(scan3)
@@ -99,3 +100,9 @@ def test_band_bounds_cover_image():
             spans = [parallel.band_bounds(h, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == h
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            # bands start on multiples of 64 rows (tile heights 16 / 8 / 4 and the blue-noise period divide it); with fewer
+            # 64-row blocks than ranks the last ranks get an empty band instead of a misaligned one
+            assert all(y0 % 64 == 0 or y0 == h for y0, _ in spans)
+            assert all(y1 >= y0 for y0, y1 in spans)
+    assert parallel.band_bounds(37, 1, 2) == (37, 37)
+    assert parallel.band_bounds(16384, 3, 8) == (6144, 8192)
