@@ -105,6 +105,22 @@ int nq_get_list_counts(nq_handle* h, uint8_t* closest_counts, uint8_t* nearest_c
 int nq_get_params(const nq_handle* h, nq_params* out);
 int nq_set_params(nq_handle* h, const nq_params* in);
 
+/* ---- the ditherers' own static entry points: the Ditherable is the handle (its kind and params answer
+ *      getColorIndex / nearestColorIndex exactly as in nq_dither) ----
+ * static int[] GilbertCurve.dither(width, height, pixels, palette, ditherable, saliencies, weight, dither)
+ *      (NQ/GilbertCurve.java:367-373): saliencies may be NULL, weight is the SIGNED constructor argument (negative = the image has
+ *      semi-transparent pixels, :60-61).  out_qpixels follows the reference (:278-279): ARGB when dither || K <= 32, palette
+ *      indices otherwise; out_index (nullable) always receives the indices.
+ * static int[] BlueNoise.dither(width, height, pixels, palette, ditherable, qPixels, weight) (NQ/BlueNoise.java:207-222):
+ *      io_qpixels holds palette indices on entry (what GilbertCurve.dither returned for !dither && K > 32) and ARGB on return.
+ * REFERENCE_SEQUENTIAL: nq_gilbert_dither starts from empty lookup caches and Random(rng_seed); nq_bluenoise_dither continues with
+ * the caches and the random stream the previous call on the handle left behind, as the two calls inside dither() do. */
+int nq_gilbert_dither(nq_handle* h, int width, int height, const uint32_t* pixels, const uint32_t* palette, int K,
+                      const float* saliencies, double weight, int dither, int64_t rng_seed, int mode,
+                      int32_t* out_qpixels, uint16_t* out_index);
+int nq_bluenoise_dither(nq_handle* h, int width, int height, const uint32_t* pixels, const uint32_t* palette, int K,
+                        int32_t* io_qpixels, float weight, int64_t rng_seed, int mode, uint16_t* out_index);
+
 /* ---- Bitmap convert(int nMaxColors, boolean dither)  (NQ/PnnQuantizer.java:409-456) ----
  * out_argb  [w*h]  : the pixels of the returned Bitmap (always ARGB)
  * out_index [w*h]  : palette index chosen per pixel (nullable)

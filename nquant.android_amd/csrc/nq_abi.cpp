@@ -93,7 +93,7 @@ GilbertConsts gilbert_consts(int K, double weight, bool hasSaliencies, bool dith
     g.thresold = DITHER_MAX > 9 ? -112 : -64;
     g.beta = beta; g.DITHER_MAX = DITHER_MAX; g.ditherMax = ditherMax;
     init_weights(g.weights, DITHER_MAX);
-    init_weights(g.w1, 1); init_weights(g.w3, 3); init_weights(g.w7, 7);
+    init_weights(g.w1, 1); init_weights(g.w3, 3); init_weights(g.w7, 7); init_weights(g.w15, 15);
     return g;
 }
 
@@ -162,6 +162,10 @@ struct nq_handle {
     DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..19] merge stats, [20..21] distinct-colour result
     DevBuf<int> live3;                // merge loop: two live lists + position index
     int use_lists = 1;
+    // nq_gilbert_dither / nq_bluenoise_dither: the static entry points of the reference run the same stages with caller-supplied
+    // saliencies / weight instead of the ones dither() derives
+    struct StageOverride { bool gilbert_only = false, blue_only = false; const float* d_sal = nullptr; bool hasSal = false; double weight = 0; float blueWeight = 1.f; } ov;
+    DevBuf<float> d_user_sal;
     int band_y0 = 0, band_image_h = 0; // nq_set_band: this handle dithers a row band of a larger image (0, 0 = a whole image)
     int use_fast_dither = 1;          // NQ_OPT_FAST_DITHER: the specialised dither kernel where the configuration allows it
     int last_dither_fast = 0;         // diagnostics: 1 if the last dither pass ran gilbert_fast_kernel
@@ -620,16 +624,19 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     // The reference negates the field once per convert() (dither() runs once per object); here dither may be called repeatedly on
     // one handle, so the negation holds for this call only and the handle keeps the value pnnquan left.
     struct WeightGuard { double& w; double saved; ~WeightGuard() { w = saved; } } weight_guard{p.weight, p.weight};
-    if (p.hasSemiTransparency) p.weight = -std::fabs(p.weight);
+    const nq_handle::StageOverride ov = h->ov;       // (the static entry points GilbertCurve.dither / BlueNoise.dither: nq_gilbert_dither ...)
+    const bool staged = ov.gilbert_only || ov.blue_only;
+    if (p.hasSemiTransparency && !staged) p.weight = -std::fabs(p.weight);
     bool hasSal = false, salSubst = false;
-    if (h->kind == NQ_KIND_LAB) {
+    if (staged) hasSal = ov.hasSal;
+    else if (h->kind == NQ_KIND_LAB) {
         if (p.nMaxColors > 2 && p.nMaxColors < 128) { hasSal = true; salSubst = true; }       // pnnquan :135,:155-156
         else if (dither && (K <= 256 || p.weight > .99)) { hasSal = true; }                   // :499-508
     }
-    const bool post = !dither && K > 32;
-    float blueWeight = 1.0f;
-    const bool seq_lab_post = post && h->kind == NQ_KIND_LAB && sequential;   // needs pixelMap.size() AFTER the gilbert pass
-    if (post && h->kind == NQ_KIND_LAB && !sequential) {
+    const bool post = ov.blue_only || (!ov.gilbert_only && !dither && K > 32);
+    float blueWeight = staged ? ov.blueWeight : 1.0f;
+    const bool seq_lab_post = !staged && post && h->kind == NQ_KIND_LAB && sequential;   // needs pixelMap.size() AFTER the gilbert pass
+    if (!staged && post && h->kind == NQ_KIND_LAB && !sequential) {
         if (p.distinctColors <= 0) {
             int64_t cnt = 0;
             int rcd = distinct_colors(h, d_argb, n, 0, &cnt, nullptr);
@@ -640,7 +647,7 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         blueWeight = delta > 0.023 ? 1.0f : (float) (37.013 * delta + 0.906);
     }
     DevParams P = dev_params(h, K);
-    GilbertConsts G = gilbert_consts(K, p.weight, hasSal, dither != 0);
+    GilbertConsts G = gilbert_consts(K, staged ? ov.weight : p.weight, hasSal, dither != 0);
     G.salSubst = salSubst;
 
     TileGeom T;
@@ -678,11 +685,12 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         if (rc) return rc;
         T.path_len[s] = sw[s] * shh[s]; T.shape_w[s] = sw[s]; T.shape_h[s] = shh[s];
     }
-    if (sequential) NQ_HIP(h, hipMemsetAsync(h->d_bincache.p, 0xFF, 65536 * sizeof(short), h->stream));
+    if (sequential && !ov.blue_only) NQ_HIP(h, hipMemsetAsync(h->d_bincache.p, 0xFF, 65536 * sizeof(short), h->stream));   // (BlueNoise.dither alone continues the caches)
     nq::ListsView lv;
     { int rcl = prepare_lists(h, P, &lv); if (rcl) return rcl; }
     const float* d_sal = nullptr;
-    if (hasSal) {
+    if (staged) d_sal = hasSal ? ov.d_sal : nullptr;
+    else if (hasSal) {
         NQ_HIP(h, h->sc->saliency.reserve((size_t) n));
         launch_saliency(P, salSubst ? 1 : 0, (const int*) d_argb, n, h->sc->saliency.p, h->stream);
         d_sal = h->sc->saliency.p;
@@ -700,6 +708,8 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     }
     const int* d_tile_list = nullptr;
     h->last_dither_fast = 0;
+    if (ov.blue_only) { /* BlueNoise.dither alone: the indices are already in d_out_index */ }
+    else {
     if (!sequential && h->use_fast_dither && gilbert_fast_eligible(P, G, T, lv)) {
         // production path (nq_dither_fast.hip); the tiles it cannot finish come back as a list for the generic kernel below
         NQ_HIP(h, h->d_failed.reserve((size_t) T.tiles_x * T.tiles_y + 1));
@@ -712,6 +722,7 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
                    h->d_scalars.p, d_out_index, post ? nullptr : (int*) d_out_argb,
                    seq_lab_post ? h->d_seqlog.p : nullptr, seq_lab_post ? h->d_seqlog.p + log_cap : nullptr,
                    seq_lab_post ? h->d_seqseen.p : nullptr, log_cap, d_tile_list, h->stream);
+    }
     rec(h, 6);
     if (seq_lab_post) {
         // pixelMap.size() at NQ/PnnLABQuantizer.java:512 = |{image colours as the histogram saw them} U {colours looked up on a
@@ -897,6 +908,66 @@ int nq_dither(nq_handle* h, const uint32_t* argb, int width, int height, const u
                        (uint32_t*) h->d_out_argb.p, h->d_out_index.p);
     if (rc) return rc;
     NQ_HIP(h, hipMemcpyAsync(out_argb, h->d_out_argb.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (out_index) NQ_HIP(h, hipMemcpyAsync(out_index, h->d_out_index.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    return NQ_OK;
+}
+
+// GilbertCurve.dither(width, height, pixels, palette, ditherable, saliencies, weight, dither) (NQ/GilbertCurve.java:367-373)
+int nq_gilbert_dither(nq_handle* h, int width, int height, const uint32_t* pixels, const uint32_t* palette, int K, const float* saliencies,
+                      double weight, int dither, int64_t rng_seed, int mode, int32_t* out_qpixels, uint16_t* out_index) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!pixels || !out_qpixels || width <= 0 || height <= 0) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    if (mode != NQ_MODE_PARALLEL_TILED && mode != NQ_MODE_REFERENCE_SEQUENTIAL) NQ_FAIL(h, NQ_ERR_INVALID, "unknown mode %d", mode);
+    const size_t n = (size_t) width * height;
+    NQ_HIP(h, h->d_in.reserve(n)); NQ_HIP(h, h->d_out_argb.reserve(n)); NQ_HIP(h, h->d_out_index.reserve(n));
+    NQ_HIP(h, hipMemcpyAsync(h->d_in.p, pixels, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (saliencies) {
+        NQ_HIP(h, h->d_user_sal.reserve(n));
+        NQ_HIP(h, hipMemcpyAsync(h->d_user_sal.p, saliencies, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    h->ov = nq_handle::StageOverride();
+    h->ov.gilbert_only = true; h->ov.hasSal = saliencies != nullptr; h->ov.d_sal = h->d_user_sal.p; h->ov.weight = weight;
+    rc = dither_device(h, (const uint32_t*) h->d_in.p, width, height, palette, K, dither, rng_seed, mode, (uint32_t*) h->d_out_argb.p, h->d_out_index.p);
+    h->ov = nq_handle::StageOverride();
+    if (rc) return rc;
+    std::vector<uint16_t> idx(n);
+    NQ_HIP(h, hipMemcpyAsync(idx.data(), h->d_out_index.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    const bool argb_out = dither || K <= 32;          // :278-279: qPixels holds ARGB only then, palette indices otherwise
+    if (argb_out) NQ_HIP(h, hipMemcpyAsync(out_qpixels, h->d_out_argb.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (!argb_out) for (size_t i = 0; i < n; ++i) out_qpixels[i] = idx[i];
+    if (out_index) std::memcpy(out_index, idx.data(), n * sizeof(uint16_t));
+    return NQ_OK;
+}
+
+// BlueNoise.dither(width, height, pixels, palette, ditherable, qPixels, weight) (NQ/BlueNoise.java:207-222): qPixels holds palette
+// indices on entry and ARGB on return
+int nq_bluenoise_dither(nq_handle* h, int width, int height, const uint32_t* pixels, const uint32_t* palette, int K, int32_t* io_qpixels,
+                        float weight, int64_t rng_seed, int mode, uint16_t* out_index) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!pixels || !io_qpixels || width <= 0 || height <= 0 || !palette || K < 1) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    if (mode != NQ_MODE_PARALLEL_TILED && mode != NQ_MODE_REFERENCE_SEQUENTIAL) NQ_FAIL(h, NQ_ERR_INVALID, "unknown mode %d", mode);
+    const size_t n = (size_t) width * height;
+    std::vector<uint16_t> idx(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (io_qpixels[i] < 0 || io_qpixels[i] >= K) NQ_FAIL(h, NQ_ERR_INVALID, "qPixels[%zu] = %d is not a palette index", i, io_qpixels[i]);
+        idx[i] = (uint16_t) io_qpixels[i];
+    }
+    NQ_HIP(h, h->d_in.reserve(n)); NQ_HIP(h, h->d_out_argb.reserve(n)); NQ_HIP(h, h->d_out_index.reserve(n));
+    NQ_HIP(h, hipMemcpyAsync(h->d_in.p, pixels, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    NQ_HIP(h, hipMemcpyAsync(h->d_out_index.p, idx.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+    NQ_HIP(h, hipStreamSynchronize(h->stream));        // idx goes out of scope
+    h->ov = nq_handle::StageOverride();
+    h->ov.blue_only = true; h->ov.blueWeight = weight; h->ov.weight = h->params.weight;
+    rc = dither_device(h, (const uint32_t*) h->d_in.p, width, height, palette, K, 0, rng_seed, mode, (uint32_t*) h->d_out_argb.p, h->d_out_index.p);
+    h->ov = nq_handle::StageOverride();
+    if (rc) return rc;
+    NQ_HIP(h, hipMemcpyAsync(io_qpixels, h->d_out_argb.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (out_index) NQ_HIP(h, hipMemcpyAsync(out_index, h->d_out_index.p, n * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
     return NQ_OK;

@@ -29,7 +29,7 @@ struct GilbertConsts {
     float beta;
     double weightAbs;       // the field `weight` (abs value, :61)
     float weights[25];      // initWeights(DITHER_MAX) (non-sorted mode)
-    float w1[1], w3[3], w7[7]; // initWeights(1|3|7) (sorted mode growth 1 -> 3 -> 7 -> 15)
+    float w1[1], w3[3], w7[7], w15[15]; // initWeights(1|3|7|15) (sorted mode growth 1 -> 3 -> 7 -> 15 -> 31)
 };
 
 struct TileGeom {

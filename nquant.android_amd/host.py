@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "nq_set_params", "nq_convert", "nq_convert_device", "nq_convert_batch_device", "nq_convert_batch", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
     "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_band_distinct_device", "nq_set_distinct", "nq_get_stage_ms", "nq_get_merge_stats",
-    "nq_get_dither_path", "nq_set_band", "nq_band_color_presence_device",
+    "nq_get_dither_path", "nq_set_band", "nq_band_color_presence_device", "nq_gilbert_dither", "nq_bluenoise_dither",
 ]
 OPT_CELL_LISTS, OPT_FAST_DITHER = 1, 2
 
@@ -119,6 +119,8 @@ def load_library():
     L.nq_get_merge_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.nq_get_dither_path.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.nq_set_band.argtypes = [vp, i32, i32]
+    L.nq_gilbert_dither.argtypes = [vp, i32, i32, vp, vp, i32, vp, C.c_double, i32, i64, i32, vp, vp]
+    L.nq_bluenoise_dither.argtypes = [vp, i32, i32, vp, vp, i32, vp, C.c_float, i64, i32, vp]
     L.nq_band_color_presence_device.argtypes = [vp, vp, i64, vp, i32, C.POINTER(C.c_int64), vp]
     _LIB = L
     return L
@@ -261,6 +263,32 @@ class PnnQuantizer:
                                       int(bool(dither)), int(self.seed if seed is None else seed),
                                       int(self.mode if mode is None else mode), out.ctypes.data, idx.ctypes.data))
         return out.reshape(self.height, self.width), idx.reshape(self.height, self.width)
+
+    def gilbert_dither(self, palette, saliencies, weight, dither, mode=None, seed=None):
+        """static int[] GilbertCurve.dither(width, height, pixels, palette, this, saliencies, weight, dither) (NQ/GilbertCurve.java:367):
+        returns (qPixels as the reference leaves them, palette indices)."""
+        palette = _as_i32(palette)
+        n = self.width * self.height
+        sal = None if saliencies is None else np.ascontiguousarray(saliencies, np.float32).reshape(-1)
+        out = np.empty(n, np.int32)
+        idx = np.empty(n, np.uint16)
+        self._check(self._L.nq_gilbert_dither(self._h, self.width, self.height, self.pixels.ctypes.data, palette.ctypes.data, len(palette),
+                                              None if sal is None else sal.ctypes.data, float(weight), int(bool(dither)),
+                                              int(self.seed if seed is None else seed), int(self.mode if mode is None else mode),
+                                              out.ctypes.data, idx.ctypes.data))
+        return out.reshape(self.height, self.width), idx.reshape(self.height, self.width)
+
+    def bluenoise_dither(self, palette, qpixels, weight, mode=None, seed=None):
+        """static int[] BlueNoise.dither(width, height, pixels, palette, this, qPixels, weight) (NQ/BlueNoise.java:207): qPixels =
+        palette indices in, returns (ARGB, final indices)."""
+        palette = _as_i32(palette)
+        n = self.width * self.height
+        io = np.ascontiguousarray(qpixels, np.int32).reshape(-1).copy()
+        idx = np.empty(n, np.uint16)
+        self._check(self._L.nq_bluenoise_dither(self._h, self.width, self.height, self.pixels.ctypes.data, palette.ctypes.data, len(palette),
+                                                io.ctypes.data, float(weight), int(self.seed if seed is None else seed),
+                                                int(self.mode if mode is None else mode), idx.ctypes.data))
+        return io.reshape(self.height, self.width), idx.reshape(self.height, self.width)
 
     def nearestColorIndex(self, palette, colors):
         """short nearestColorIndex(palette, c, pos) on a cache miss, vectorised over `colors`."""

@@ -29,19 +29,31 @@ JNIEXPORT void JNICALL Java_com_android_nQuant_PnnQuantizer_nqDestroy(JNIEnv* en
 JNIEXPORT jintArray JNICALL Java_com_android_nQuant_PnnQuantizer_nqConvert(JNIEnv* env, jclass c, jlong hh, jintArray argb,
         jint w, jint hgt, jint nMaxColors, jboolean dither, jlong seed, jint mode, jintArray outArgb, jshortArray outIndex) {
     nq_handle* h = (nq_handle*) (intptr_t) hh;
-    static uint32_t palette[32768];
+    const int cap = nMaxColors > 2 ? nMaxColors : 2;
+    uint32_t* palette = (uint32_t*) malloc((size_t) cap * sizeof(uint32_t));     /* per call: two threads may convert different objects at once */
+    if (!palette) { throw_rt(env, "out of memory"); return NULL; }
     int32_t K = 0;
-    jint* in = (*env)->GetPrimitiveArrayCritical(env, argb, NULL);         /* the reference's int[] pixels, no copy */
-    jint* out = (*env)->GetPrimitiveArrayCritical(env, outArgb, NULL);
-    jshort* idx = outIndex ? (*env)->GetPrimitiveArrayCritical(env, outIndex, NULL) : NULL;
+    /* The convert blocks on the GPU for up to seconds (the merge loop): plain Get/Release<Type>ArrayElements, not critical regions --
+     * a critical region must be short and non-blocking and would stall the collector JVM-wide for the whole call. */
+    jint* in = (*env)->GetIntArrayElements(env, argb, NULL);
+    jint* out = (*env)->GetIntArrayElements(env, outArgb, NULL);
+    jshort* idx = outIndex ? (*env)->GetShortArrayElements(env, outIndex, NULL) : NULL;
+    if (!in || !out || (outIndex && !idx)) {
+        if (idx) (*env)->ReleaseShortArrayElements(env, outIndex, idx, JNI_ABORT);
+        if (out) (*env)->ReleaseIntArrayElements(env, outArgb, out, JNI_ABORT);
+        if (in) (*env)->ReleaseIntArrayElements(env, argb, in, JNI_ABORT);
+        free(palette);
+        return NULL;                                                             /* OutOfMemoryError already pending */
+    }
     int rc = nq_convert(h, (const uint32_t*) in, w, hgt, nMaxColors, dither ? 1 : 0, seed, mode,
                         (uint32_t*) out, (uint16_t*) idx, palette, &K);
-    if (idx) (*env)->ReleasePrimitiveArrayCritical(env, outIndex, idx, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, outArgb, out, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, argb, in, JNI_ABORT);           /* the input is never modified */
-    if (rc != NQ_OK) { throw_rt(env, nq_last_error(h)); return NULL; }        /* convert() `throws Exception` */
+    if (idx) (*env)->ReleaseShortArrayElements(env, outIndex, idx, 0);
+    (*env)->ReleaseIntArrayElements(env, outArgb, out, 0);
+    (*env)->ReleaseIntArrayElements(env, argb, in, JNI_ABORT);                   /* the input is never modified */
+    if (rc != NQ_OK) { free(palette); throw_rt(env, nq_last_error(h)); return NULL; }        /* convert() `throws Exception` */
     jintArray pal = (*env)->NewIntArray(env, K);
-    (*env)->SetIntArrayRegion(env, pal, 0, K, (const jint*) palette);
+    if (pal) (*env)->SetIntArrayRegion(env, pal, 0, K, (const jint*) palette);
+    free(palette);
     return pal;
 }
 

@@ -1511,6 +1511,52 @@ int nqo_dither_tile_rows(nqo_quantizer* q, const int32_t* palette, int K, int di
     return dither_impl(q, palette, K, dither, tile_w, tile_h, row_first, row_count, out_argb, out_index);
 }
 
+/* The ditherers' static entry points with caller-supplied saliencies / weight (NQ/GilbertCurve.java:367-373, NQ/BlueNoise.java:207-222);
+ * the quantizer object is the Ditherable.  tile_w/tile_h <= 0: one curve over the image with the object's caches and Random (they are
+ * NOT cleared here, so a following nqo_bluenoise_dither_stage continues them as inside dither()); > 0: the tiled restatement. */
+int nqo_gilbert_dither_stage(nqo_quantizer* q, const int32_t* palette, int K, const float* saliencies, double weight, int dither,
+                             int tile_w, int tile_h, int32_t* out_qpixels, int32_t* out_index) {
+    const size_t N = (size_t) q->width * q->height;
+    const int tiled = tile_w > 0 && tile_h > 0;
+    ditherable dth = {q, dither, &q->rng};
+    int32_t* qIndex = calloc(N ? N : 1, sizeof(int32_t));
+    if (!tiled) {
+        imap_clear(&q->closestMap); imap_clear(&q->nearestMap);
+        gilbert_run(q, &dth, palette, K, saliencies, weight, dither, qIndex, 0, 0, q->width, q->height);
+    } else {
+        q->no_cache = 1;
+        int64_t tile_rng;
+        int tix = 0;
+        for (int ty = 0; ty < q->height; ty += tile_h)
+            for (int tx = 0; tx < q->width; tx += tile_w, ++tix) {
+                int tw = q->width - tx < tile_w ? q->width - tx : tile_w;
+                int th = q->height - ty < tile_h ? q->height - ty : tile_h;
+                nqo_jrandom_seed(&tile_rng, (int64_t) mix64((uint64_t) q->seed + (uint64_t) tix));
+                dth.rng = &tile_rng;
+                gilbert_run(q, &dth, palette, K, saliencies, weight, dither, qIndex, tx, ty, tw, th);
+            }
+        q->no_cache = 0;
+    }
+    for (size_t i = 0; i < N; ++i) out_qpixels[i] = (dither || K <= 32) ? palette[qIndex[i]] : qIndex[i];     /* :278-279 */
+    if (out_index) memcpy(out_index, qIndex, N * sizeof(int32_t));
+    free(qIndex);
+    return 0;
+}
+int nqo_bluenoise_dither_stage(nqo_quantizer* q, const int32_t* palette, int K, int32_t* io_qpixels, float weight, int tiled,
+                               int32_t* out_index) {
+    const size_t N = (size_t) q->width * q->height;
+    ditherable dth = {q, 0, &q->rng};
+    int32_t* qIndex = malloc((N ? N : 1) * sizeof(int32_t));
+    memcpy(qIndex, io_qpixels, N * sizeof(int32_t));
+    if (tiled) q->no_cache = 1;
+    bluenoise_dither(q, &dth, palette, K, qIndex, io_qpixels, weight, tiled, 0, q->height);
+    q->no_cache = 0;
+    if (out_index) memcpy(out_index, qIndex, N * sizeof(int32_t));
+    free(qIndex);
+    imap_clear(&q->closestMap); imap_clear(&q->nearestMap);
+    return 0;
+}
+
 /* NQ/PnnQuantizer.java:410-436 */
 void nqo_prescan(nqo_quantizer* q, int nMaxColors) {
     double t0 = now_s();

@@ -82,6 +82,12 @@ int  nqo_dither_tile_rows(nqo_quantizer* q, const int32_t* palette, int K, int d
 /* diagnostics: event counters of the per-pixel pass (tools/oracle_event_rates.py) */
 void nqo_debug_counters(int64_t* out16, int reset);
 
+/* static GilbertCurve.dither / BlueNoise.dither with caller-supplied saliencies (nullable) and weight; tile <= 0 = sequential */
+int  nqo_gilbert_dither_stage(nqo_quantizer* q, const int32_t* palette, int K, const float* saliencies, double weight, int dither,
+                              int tile_w, int tile_h, int32_t* out_qpixels, int32_t* out_index);
+int  nqo_bluenoise_dither_stage(nqo_quantizer* q, const int32_t* palette, int K, int32_t* io_qpixels, float weight, int tiled,
+                                int32_t* out_index);
+
 /* Pure lookups with cache-miss semantics (memo cleared before every colour). */
 void nqo_nearest_index(nqo_quantizer* q, const int32_t* palette, int K, const int32_t* colors, int64_t M,
                        int16_t* out_index);

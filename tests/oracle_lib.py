@@ -42,6 +42,8 @@ def lib():
     L.nqo_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
     L.nqo_destroy.argtypes = [C.c_void_p]
     L.nqo_set_seed.argtypes = [C.c_void_p, C.c_int64]
+    L.nqo_gilbert_dither_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.nqo_bluenoise_dither_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
     L.nqo_set_bands.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.nqo_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.nqo_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
@@ -171,6 +173,23 @@ class OracleQuantizer:
         self._L.nqo_dither_tile_rows(self._h, palette.ctypes.data, len(palette), int(dither), int(tile[0]), int(tile[1]),
                                      int(row_first), int(row_count), out.ctypes.data, idx.ctypes.data)
         return out.reshape(self.height, self.width), idx.reshape(self.height, self.width)
+
+    def gilbert_dither_stage(self, palette, saliencies, weight, dither, tile=None):
+        palette = _i32(palette)
+        n = self.width * self.height
+        sal = None if saliencies is None else np.ascontiguousarray(saliencies, np.float32).reshape(-1)
+        out = np.zeros(n, np.int32); idx = np.zeros(n, np.int32)
+        tw, th = (0, 0) if tile is None else tile
+        self._L.nqo_gilbert_dither_stage(self._h, palette.ctypes.data, len(palette), None if sal is None else sal.ctypes.data, float(weight),
+                                         int(dither), int(tw), int(th), out.ctypes.data, idx.ctypes.data)
+        return out.reshape(self.height, self.width), idx.reshape(self.height, self.width)
+
+    def bluenoise_dither_stage(self, palette, qpixels, weight, tiled):
+        palette = _i32(palette)
+        io = np.ascontiguousarray(qpixels, np.int32).reshape(-1).copy()
+        idx = np.zeros(io.size, np.int32)
+        self._L.nqo_bluenoise_dither_stage(self._h, palette.ctypes.data, len(palette), io.ctypes.data, float(weight), int(tiled), idx.ctypes.data)
+        return io.reshape(self.height, self.width), idx.reshape(self.height, self.width)
 
     def nearest_index(self, palette, colors):
         palette, colors = _i32(palette), _i32(colors).ravel()

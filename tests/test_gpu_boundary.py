@@ -1,0 +1,159 @@
+"""The drop-in boundary itself: the ditherers' static entry points (GilbertCurve.dither / BlueNoise.dither with
+caller-supplied saliencies and signed weight) against the oracle's, a plain-C caller of include/nquant_abi.h (what a JNI / cgo
+binding does, no Python in between), the host-buffer batch entry against the oracle, and the indexed-PNG writer on a GPU result."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from nquant.android_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SEQ, TILED = 0, 1
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _copy_params(src, dst_cls):
+    p = dst_cls()
+    for f, _ in dst_cls._fields_:
+        setattr(p, f, getattr(src, f))
+    return p
+
+
+def _sal(shape, seed):
+    z = synth.splitmix64(seed, shape[0] * shape[1])
+    return (0.1 + 0.9 * (z & np.uint64(0xFFFF)).astype(np.float64) / 65535.0).astype(np.float32).reshape(shape)
+
+
+STAGE_CASES = [  # kind, K, image, saliencies?, signed weight, dither, mode/tile, BlueNoise weight (None: no second stage)
+    (1, 256, lambda: synth.gradient_noise(96, 64, 301), True, 0.0115, True, (8, 8), None),
+    (1, 256, lambda: synth.gradient_noise(96, 64, 302), False, 0.0115, True, (8, 8), None),          # saliencies == null
+    (1, 256, lambda: synth.gradient_noise(80, 64, 303), True, 0.0115, False, (8, 8), 0.95),           # indices out, then BlueNoise.dither
+    (1, 64, lambda: synth.with_alpha(synth.gradient_noise(64, 64, 304), 304), True, -0.3, True, (16, 16), None),   # weight < 0: semi-transparency ladder
+    (1, 16, lambda: synth.gradient_noise(64, 48, 305), True, 0.02, True, None, None),                 # sequential, K <= 32 branch
+    (0, 64, lambda: synth.gradient_noise(64, 48, 306), False, 0.5, False, None, 1.0),                 # RGB sequential + BlueNoise with continued caches
+    (0, 16, lambda: synth.uniform_rgb(48, 48, 307), False, 0.004, False, (8, 8), None),
+    (1, 256, lambda: synth.uniform_rgb(64, 64, 308), True, 0.995, True, (4, 4), None),                # weight > .99 rung
+]
+
+
+@pytest.mark.parametrize("kind,K,mk,with_sal,weight,dither,tile,blue_w", STAGE_CASES)
+def test_static_ditherer_entry_points_vs_oracle(nq, oracle, kind, K, mk, with_sal, weight, dither, tile, blue_w):
+    img = mk()
+    seed = 99
+    oq = oracle.OracleQuantizer(kind, img, seed=seed)
+    oq.prescan(K)
+    pal = oq.pnnquan(K)
+    params = _copy_params(oq.params, nq.Params)
+    sal = _sal(img.shape, 1000 + K) if with_sal else None
+    oq.set_seed(seed)
+    want_q, want_idx = oq.gilbert_dither_stage(pal, sal, weight, dither, tile=tile)
+    mode = SEQ if tile is None else TILED
+    gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=mode, seed=seed, tile=tile)
+    gq.set_params(params)
+    got_q, got_idx = gq.gilbert_dither(pal, sal, weight, dither)
+    assert (got_idx.astype(np.int32) == want_idx).all(), "indices: %d mismatches" % int((got_idx.astype(np.int32) != want_idx).sum())
+    assert (got_q == want_q).all()
+    if dither or len(pal) <= 32:
+        assert (got_q == pal[got_idx]).all()             # :278-279 ARGB
+    else:
+        assert (got_q == got_idx).all()                  # indices
+    if blue_w is not None and not dither and len(pal) > 32:
+        want_argb, want_i2 = oq.bluenoise_dither_stage(pal, want_q, blue_w, tile is not None)
+        got_argb, got_i2 = gq.bluenoise_dither(pal, got_q, blue_w)
+        assert (got_i2.astype(np.int32) == want_i2).all()
+        assert (got_argb == want_argb).all()
+
+
+def test_plain_c_caller_of_the_abi(nq, oracle, tmp_path):
+    """tests/c/c_abi_smoke.c, compiled with gcc against include/nquant_abi.h and libnquant_hip.so: nq_create / nq_set_tile /
+    nq_convert / nq_get_params / nq_last_error / nq_destroy from C; its palette and index map are then checked against the oracle."""
+    lib = nq.library_path()
+    exe = str(tmp_path / "c_abi_smoke")
+    torch_lib = ""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        torch_lib = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    except Exception:
+        pass
+    rpaths = [os.path.dirname(lib), "/opt/rocm/lib"]
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "c_abi_smoke.c"),
+           "-o", exe, lib, "-Wl,--allow-shlib-undefined"] + ["-Wl,-rpath," + r for r in rpaths]
+    subprocess.check_call(cmd)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = ":".join(["/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
+    out = str(tmp_path / "out.bin")
+    r = subprocess.run([exe, out], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "c_abi_smoke ok" in r.stdout
+    raw = open(out, "rb").read()
+    k = int(np.frombuffer(raw[:4], np.int32)[0])
+    pal = np.frombuffer(raw[4:4 + 4 * k], np.int32)
+    W, H = 96, 64
+    idx = np.frombuffer(raw[4 + 4 * k:4 + 4 * k + 2 * W * H], np.uint16).reshape(H, W)
+    img = np.frombuffer(raw[4 + 4 * k + 2 * W * H:], np.int32).reshape(H, W)
+    oq = oracle.OracleQuantizer(1, img, seed=7)
+    oq.prescan(256)
+    want_pal = oq.pnnquan(256)
+    oq.set_seed(7)
+    _, want_idx = oq.dither(want_pal, True, tile=(8, 8))
+    assert len(want_pal) == k and (want_pal == pal).all()
+    assert (idx.astype(np.int32) == want_idx).all()
+
+
+def test_convert_batch_host_buffers_vs_oracle(nq, oracle):
+    """nq_convert_batch (host buffers in, host buffers out) against the oracle, image by image."""
+    import torch
+    imgs = [(1, synth.gradient_noise(96 + 8 * i, 80, 320 + i)) for i in range(4)] + [(0, synth.uniform_rgb(64, 72, 330))]
+    qs = []
+    for i, (kind, im) in enumerate(imgs):
+        q = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(np.zeros((1, 1), np.int32), mode=TILED, seed=21 + i, tile=(8, 8))
+        q.height, q.width = im.shape
+        qs.append(q)
+    h_in = [torch.from_numpy(np.ascontiguousarray(im).reshape(-1).copy()).pin_memory() for _, im in imgs]
+    h_out = [torch.zeros(t.numel(), dtype=torch.int32).pin_memory() for t in h_in]
+    h_idx = [torch.zeros(t.numel(), dtype=torch.int16).pin_memory() for t in h_in]
+    pals = nq.convert_batch_host(qs, [t.data_ptr() for t in h_in], 256, True, [t.data_ptr() for t in h_out], [t.data_ptr() for t in h_idx])
+    for i, (kind, im) in enumerate(imgs):
+        oq = oracle.OracleQuantizer(kind, im, seed=21 + i)
+        oq.prescan(256)
+        want_pal = oq.pnnquan(256)
+        want_argb, want_idx = oq.dither(want_pal, True, tile=(8, 8))
+        assert (pals[i] == want_pal).all(), i
+        assert (h_idx[i].numpy().view(np.uint16).reshape(im.shape).astype(np.int32) == want_idx).all(), i
+        assert (h_out[i].numpy().reshape(im.shape) == want_argb).all(), i
+
+
+def test_indexed_png_of_a_gpu_result_decodes_to_the_oracle_index_map(nq, oracle, tmp_path):
+    """palette + u8 indices as an indexed PNG -- written from a GPU convert, decoded, compared with the ORACLE's
+    index map and palette (incl. the transparent entry -> tRNS)."""
+    import struct
+    import zlib
+    from nquant.android_amd.indexed_png import write_indexed_png
+    img = synth.with_alpha(synth.gradient_noise(120, 72, 340), 340, p_transparent=0.03, p_semi=0.0)
+    seed = 8
+    oq = oracle.OracleQuantizer(1, img, seed=seed)
+    oq.prescan(256)
+    want_pal = oq.pnnquan(256)
+    _, want_idx = oq.dither(want_pal, True, tile=(8, 8))
+    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=seed, tile=(8, 8))
+    out = gq.convert(256, True)
+    path = str(tmp_path / "q.png")
+    write_indexed_png(path, out.index, out.palette)
+    data = open(path, "rb").read()
+    pos, chunks = 8, {}
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        chunks[tag] = chunks.get(tag, b"") + data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    w, h = struct.unpack(">II", chunks[b"IHDR"][:8])
+    raw = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), np.uint8).reshape(h, w + 1)[:, 1:]
+    assert (raw.astype(np.int32) == want_idx).all()
+    plte = np.frombuffer(chunks[b"PLTE"], np.uint8).reshape(-1, 3)
+    wp = want_pal.view(np.uint32)
+    assert (plte == np.stack([(wp >> 16) & 0xFF, (wp >> 8) & 0xFF, wp & 0xFF], axis=1)).all()
+    trns = np.frombuffer(chunks[b"tRNS"], np.uint8)
+    assert len(trns) == len(wp) and (trns == ((wp >> 24) & 0xFF)).all() and (trns != 255).any()
