@@ -9,12 +9,19 @@ Device memory: batch x 160 MiB of pixel buffers (in, out, index) + 10 MiB of qua
 Multi-GPU (driver: torch.distributed.run, one rank per GPU): every rank converts its own batches (independent units,
 no data-path collective; RCCL only for the barrier / max-over-ranks of the time) -> "scaling": "weak".
 
-Prints ONE JSON line on rank 0 (contract in the round prompt) with two extra objects:
-  roofline     -- dominant per-pixel kernel (gilbert_kernel = nearest-colour + dither pass), algorithmic bytes
-                  8 B/pixel (4 B ARGB read + 4 B ARGB write) / its average duration measured with HIP
-                  events on the launch stream inside the timed region, against the 8 TB/s HBM peak;
-  cpu_baseline -- the CPU oracle (C restatement of the reference's sequential Java path, 1 core) on a bounded sample
-                  of the same workload, rank 0, N=1 only.
+Prints ONE JSON line on rank 0 (contract in the round prompt) with extra objects:
+  roofline       -- dominant per-pixel kernel (gilbert_fast_kernel = nearest-colour + dither pass), algorithmic bytes
+                    8 B/pixel (4 B ARGB read + 4 B ARGB write) / its average duration measured with HIP
+                    events on the launch stream inside the timed region, against the 8 TB/s HBM peak;
+  roofline_whole -- the same 8 B/pixel against the time of the WHOLE convert per image (all stages);
+  cpu_baseline   -- the CPU oracle (C restatement of the reference's sequential Java path, 1 core) on a bounded sample
+                    of the same workload (the sample size is in its "sample" field), rank 0, N=1 only.
+
+--config cfg3 (default) is the headline above.  The other two BASELINE configurations exercise the multi-GPU shapes:
+  --config cfg4  batch of 64 x 1920x1080 frames, frame f on rank f mod N (independent units, no data-path collective; strong scaling);
+  --config cfg5  one 16384x16384 image cut into N row bands: pre-scan all-reduce + all-gather of the 2.6 MB histogram partials
+                 (RCCL), the palette built on every rank, every rank dithers its band (strong scaling); the collectives are inside
+                 the timed region and their bytes / time are reported in "collectives".
 """
 import argparse
 import json
@@ -51,8 +58,8 @@ def cpu_baseline(workload, sample):
     dt = time.perf_counter() - t0
     st = q.stage_seconds()
     return {"value": round(sample * sample / dt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": "%dx%d %s, whole convert(256,true), sequential C restatement of the reference Java path, %.1f s "
-                      "(pnnquan %.1f s, dither %.1f s)" % (sample, sample, workload, dt,
+            "sample": "%dx%d %s (a bounded sample, NOT the 4096x4096 image of the headline), whole convert(256,true), sequential C "
+                      "restatement of the reference Java path, %.1f s (pnnquan %.1f s, dither %.1f s)" % (sample, sample, workload, dt,
                                                             st["histogram"] + st["nn_init"] + st["merge"], st["gilbert"]),
             "nproc": os.cpu_count()}
 
@@ -76,6 +83,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="one step = one batch of --batch images through the whole hot path")
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg4", "cfg5"],
+                    help="BASELINE.json configuration: cfg3 = the headline (4096^2 batches), cfg4 = 64 x 1920x1080 frames sharded over the "
+                         "ranks, cfg5 = one 16384^2 image in row bands with the RCCL histogram exchange")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform"])
     ap.add_argument("--tile", type=int, default=0, help="tile side of the PARALLEL_TILED decomposition (0 = automatic)")
@@ -101,6 +111,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    elif args.config == "cfg5":
+        import torch.distributed as dist       # the band pipeline always talks through a process group (world 1 here)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)
 
     import threading
     import nquant.android_amd as nq
@@ -112,6 +127,11 @@ def main():
         if rank == 0:
             nq.build_library()
         dist.barrier()
+
+    if args.config == "cfg4":
+        return bench_cfg4(args, nq, synth, dist, rank, local_rank, world)
+    if args.config == "cfg5":
+        return bench_cfg5(args, nq, synth, dist, rank, local_rank, world)
 
     W = H = args.size
     npx = W * H
@@ -245,11 +265,15 @@ def main():
             "single_convert_stages_ms": {k: round(v, 3) for k, v in single_stages.items()},
             "merge_stats": single_merge_stats,
             "pass_mpixels_s": round(npx / (kernel_ms * 1e-3) / 1e6, 1) if kernel_ms > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "gilbert_kernel<false,25> (per-pixel nearest/closest colour + error diffusion)",
+            "roofline": {"bound": "hbm", "kernel": "gilbert_fast_kernel (per-pixel nearest/closest colour + error diffusion, csrc/nq_dither_fast.hip)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": measured_traffic(W, H),
                          "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * npx, "kernel_ms": round(kernel_ms, 3)},
         }
+        whole_ms = dt / images * 1e3 * world        # time one rank spends per image, all stages
+        line["roofline_whole"] = {"bound": "hbm", "what": "8 B/pixel over the whole convert() of one image (all stages, batch amortised)",
+                                  "achieved": round(BYTES_PER_PIXEL * npx / (whole_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(BYTES_PER_PIXEL * npx / (whole_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "ms_per_image": round(whole_ms, 3)}
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
         else:
@@ -257,6 +281,133 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _barrier(dist):
+    torch.cuda.synchronize()
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(dt, dist):
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def bench_cfg4(args, nq, synth, dist, rank, local_rank, world):
+    """BASELINE cfg 4: 64 frames of 1920x1080 (type (b), seeds 100 + f), LAB 256 colours + dither, frame f on rank f mod N.  One step =
+    the whole batch once (every rank converts its frames in one nq_convert_batch_device call); no data-path collective."""
+    from nquant.android_amd import parallel
+    W, H, frames = 1920, 1080, 64
+    npx = W * H
+    mine = parallel.shard_frames(frames, rank, world)
+    slots = []
+    for f in mine:
+        q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), device=local_rank, mode=nq.MODE_PARALLEL_TILED, seed=100 + f)
+        q.width, q.height = W, H
+        slots.append({"q": q, "in": synth.gradient_noise_torch(W, H, 100 + f), "out": torch.empty(npx, dtype=torch.int32, device="cuda"),
+                      "idx": torch.empty(npx, dtype=torch.int16, device="cuda")})
+    st = torch.cuda.Stream()
+    slots[0]["q"].set_stream(st.cuda_stream)
+
+    def step():
+        return nq.convert_batch_device([s["q"] for s in slots], [s["in"].data_ptr() for s in slots], 256, True,
+                                       [s["out"].data_ptr() for s in slots], [s["idx"].data_ptr() for s in slots])
+    for _ in range(args.warmup):
+        step()
+    _barrier(dist)
+    t0 = time.perf_counter()
+    dither_ms = 0.0
+    for _ in range(args.steps):
+        pals = step()
+        dither_ms += sum(s["q"].stage_ms()["dither"] for s in slots)
+    _barrier(dist)
+    dt = _max_over_ranks(time.perf_counter() - t0, dist)
+    palt = torch.from_numpy(pals[0]).cuda()
+    if not bool((palt[(slots[0]["idx"].to(torch.int64) & 0xFFFF)] == slots[0]["out"]).all()):
+        raise SystemExit("bench cfg4: output pixels do not match palette[index]")
+    if rank == 0:
+        kernel_ms = dither_ms / (args.steps * len(slots))
+        achieved = BYTES_PER_PIXEL * npx / (kernel_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "Mpixels/sec, batch of 64 x 1920x1080 RGBA -> 256-colour PnnLAB + dither, frames sharded over the GPUs",
+            "value": round(args.steps * frames * npx / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg 4: 64 frames of 1920x1080 ARGB_8888 gradient_noise (seeds 100 + f), PnnLABQuantizer.convert(256, "
+                                   "dither=true), PARALLEL_TILED automatic tiles (4x4); frame f on rank f mod N, one nq_convert_batch_device call per rank and step",
+                       "frames": frames, "frames_per_rank": len(slots), "parallelism": "independent frames per GPU, no collective",
+                       "frames_per_s": round(args.steps * frames / dt, 2)},
+            "roofline": {"bound": "hbm", "kernel": "gilbert_fast_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * npx,
+                         "kernel_ms": round(kernel_ms, 4)},
+            "cpu_baseline": None}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_cfg5(args, nq, synth, dist, rank, local_rank, world):
+    """BASELINE cfg 5: one 16384x16384 image (type (b), seed 5) in N row bands (cut at multiples of 64 rows): pre-scan all-reduce,
+    all-gather of the f64 histogram partials (65536 x 5 x 8 B = 2.6 MB per rank), the palette built on every rank (the merge loop is
+    a sequential chain: replicated, not sharded), every rank dithers its band.  One step = the whole image once."""
+    from nquant.android_amd import parallel
+    W = H = 16384
+    y0, y1 = parallel.band_bounds(H, rank, world)
+    rows = y1 - y0
+    # the band of this rank, generated on the device from the same per-pixel stream as the whole image (offset = first pixel)
+    d_band = synth.gradient_noise_torch(W, H, 5, row0=y0, rows=rows)
+    d_out = torch.empty(max(rows * W, 1), dtype=torch.int32, device="cuda")
+    d_idx = torch.empty(max(rows * W, 1), dtype=torch.int16, device="cuda")
+    q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), device=local_rank, mode=nq.MODE_PARALLEL_TILED, seed=5)
+    st = torch.cuda.Stream()
+    q.set_stream(st.cuda_stream)
+    timings = {}
+
+    def step():
+        with torch.cuda.stream(st):
+            return parallel.convert_banded(q, d_band, W, rows, y0, 256, True, d_out, d_idx, image_height=H, timings=timings)
+    for _ in range(args.warmup):
+        step()
+    timings.clear()
+    _barrier(dist)
+    t0 = time.perf_counter()
+    dither_ms = 0.0
+    for _ in range(args.steps):
+        pal = step()
+        torch.cuda.synchronize()
+        dither_ms += q.stage_ms()["dither"]
+    _barrier(dist)
+    dt = _max_over_ranks(time.perf_counter() - t0, dist)
+    palt = torch.from_numpy(pal).cuda()
+    if rows and not bool((palt[(d_idx.to(torch.int64) & 0xFFFF)] == d_out).all()):
+        raise SystemExit("bench cfg5: output pixels do not match palette[index]")
+    if rank == 0:
+        kernel_ms = dither_ms / args.steps
+        band_px = rows * W
+        achieved = BYTES_PER_PIXEL * band_px / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        hist_bytes = 65536 * 5 * 8
+        print(json.dumps({
+            "metric": "Mpixels/sec, 16384x16384 RGBA tiled across the GPUs -> 256-colour PnnLAB + dither (RCCL histogram exchange)",
+            "value": round(args.steps * W * H / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg 5: one 16384x16384 ARGB_8888 gradient_noise image (seed 5) in %d row bands of <= %d rows; per step: band "
+                                   "pre-scan -> all-gather of 3 int64 -> band histogram -> all-gather of the 2.6 MB f64 partials -> palette on every rank "
+                                   "(merge loop replicated) -> dither of the band with global tile indices" % (world, rows),
+                       "parallelism": "row bands, one exchange step (RCCL all-gather), merge loop replicated", "palette": int(len(pal))},
+            "collectives": {"per_step_bytes_received_per_rank": world * (hist_bytes + 24), "histogram_partial_bytes": hist_bytes,
+                            "seconds_per_step_in_collectives": round(timings.get("collectives", 0.0) / args.steps, 6),
+                            "seconds_per_step_palette_build": round(timings.get("palette", 0.0) / args.steps, 6),
+                            "seconds_per_step_band_dither": round(timings.get("dither", 0.0) / args.steps, 6)},
+            "roofline": {"bound": "hbm", "kernel": "gilbert_fast_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * band_px,
+                         "kernel_ms": round(kernel_ms, 4)},
+            "cpu_baseline": None}))
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -168,6 +168,7 @@ struct nq_handle {
     DevBuf<float> d_user_sal;
     int band_y0 = 0, band_image_h = 0; // nq_set_band: this handle dithers a row band of a larger image (0, 0 = a whole image)
     int use_fast_dither = 1;          // NQ_OPT_FAST_DITHER: the specialised dither kernel where the configuration allows it
+    bool dither_events_fresh = false; // the last call on the handle was a stand-alone dither (events 5..7 are newer than stage_ms)
     int last_dither_fast = 0;         // diagnostics: 1 if the last dither pass ran gilbert_fast_kernel
     int last_dither_failed_tiles = 0; // ... and how many tiles it handed back to the generic kernel (read lazily)
     DevBuf<int> d_failed;             // {count, tile indices...} of those tiles
@@ -762,6 +763,7 @@ void finish_timing(nq_handle* h) {
     float tot = 0;
     if (hipEventElapsedTime(&tot, h->ev[0], h->ev[7]) != hipSuccess) tot = 0;
     h->stage_ms[7] = tot;
+    h->dither_events_fresh = false;
 }
 
 } // namespace
@@ -865,6 +867,12 @@ int nq_get_merge_stats(const nq_handle* h, int64_t* out8) {
 int nq_get_stage_ms(const nq_handle* h, float* out8) {
     if (!h || !out8) return NQ_ERR_INVALID;
     std::memcpy(out8, h->stage_ms, sizeof h->stage_ms);
+    if (h->dither_events_fresh) {
+        // a stand-alone nq_dither[_device] call (asynchronous: no finish_timing there): its two stages, once their events have completed
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev[5], h->ev[6]) == hipSuccess) out8[5] = ms;
+        if (hipEventElapsedTime(&ms, h->ev[6], h->ev[7]) == hipSuccess) out8[6] = ms;
+    }
     return NQ_OK;
 }
 
@@ -892,6 +900,7 @@ int nq_dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height
     if (!h) return NQ_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
+    h->dither_events_fresh = true;
     return dither_device(h, d_argb, width, height, palette, K, dither, rng_seed, mode, d_out_argb, d_out_index);
 }
 

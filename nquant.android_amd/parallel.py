@@ -133,14 +133,23 @@ def image_distinct_count(q, d_band, n, device, group=None, cap_other=65536):
     return opaque + len(others)
 
 
-def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_argb, d_out_index=None, group=None, image_height=None):
+def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_argb, d_out_index=None, group=None, image_height=None,
+                   timings=None):
     """One image tiled over the ranks of `group` (GPU only).  q: a PnnQuantizer/PnnLABQuantizer of this rank; d_band: this
     rank's rows [y0, y0 + band_rows) as a CUDA int32 tensor (band_rows may be 0: the rank then only takes part in the collectives);
     image_height: rows of the whole image (default: the sum of the bands' rows).  Bands must start on multiples of the tile height
     (band_bounds cuts at multiples of 64).  Returns the (shared) palette; the band's pixels equal rows [y0, y0 + band_rows) of the
-    single-GPU PARALLEL_TILED convert of the whole image given the same palette."""
+    single-GPU PARALLEL_TILED convert of the whole image given the same palette.  timings (optional dict): seconds spent in the
+    collectives / the palette build / the band dither are added to its "collectives" / "palette" / "dither" entries (bench.py)."""
     import ctypes as C
+    import time as _time
     L = q._L
+
+    def _tick(key, t0):
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings[key] = timings.get(key, 0.0) + (_time.perf_counter() - t0)
+    
     n = width * band_rows
     dev = d_out_argb.device if band_rows == 0 else d_band.device
     if image_height is None:
@@ -149,12 +158,21 @@ def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_ar
     scan3 = torch.tensor([-1, -1, 0], dtype=torch.int64, device=dev)
     if n > 0:
         q._check(L.nq_band_scan_device(q._h, C.c_void_p(d_band.data_ptr()), n, y0 * width, nMaxColors, C.c_void_p(scan3.data_ptr())))
+    if timings is not None:
+        torch.cuda.synchronize()
+    t0 = _time.perf_counter()
     idx, color, semi = reduce_scan(scan3, group)
+    _tick("collectives", t0)
     q._check(L.nq_set_scan(q._h, nMaxColors, idx, C.c_uint32(color & 0xFFFFFFFF), semi))
     hist = torch.zeros(HIST_BINS * HIST_STRIDE, dtype=torch.float64, device=dev)
     if n > 0:
         q._check(L.nq_band_histogram_device(q._h, C.c_void_p(d_band.data_ptr()), n, C.c_void_p(hist.data_ptr())))
+    if timings is not None:
+        torch.cuda.synchronize()
+    t0 = _time.perf_counter()
     hists = gather_histograms(hist, group)
+    _tick("collectives", t0)
+    t0 = _time.perf_counter()
     if q.KIND == 1 and int((hists.view(hists.shape[0], HIST_BINS, HIST_STRIDE)[:, :, 0].sum(0) > 0).sum()) <= nMaxColors:
         # NQ/PnnLABQuantizer.java:193-206: with so few occupied bins the image may hold <= nMaxColors distinct colours, and the
         # reference then returns them as they are -- every rank takes this branch together (the gathered histograms are identical)
@@ -167,6 +185,8 @@ def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_ar
     q._check(L.nq_palette_from_histograms_device(q._h, C.c_void_p(hists.data_ptr()), hists.shape[0], nMaxColors,
                                                  pal.ctypes.data, C.byref(K)))
     pal = pal[:K.value].copy()
+    _tick("palette", t0)
+    t0 = _time.perf_counter()
     if q.KIND == 1 and not dither and K.value > 32:
         # BlueNoise weight of convert(n, false): delta = K^2 / pixelMap.size() over the WHOLE image (NQ/PnnLABQuantizer.java:511-515)
         total = image_distinct_count(q, d_band, n, dev, group)
@@ -181,4 +201,5 @@ def convert_banded(q, d_band, width, band_rows, y0, nMaxColors, dither, d_out_ar
             q.dither_device(d_band.data_ptr(), pal, dither, d_out_argb.data_ptr(), d_out_index.data_ptr() if d_out_index is not None else 0)
         finally:
             q.set_band(0, 0)
+    _tick("dither", t0)
     return pal

@@ -70,10 +70,11 @@ def few_colors(width, height, seed, ncolors):
     return pal[(z % np.uint64(ncolors)).astype(np.int64)].view(np.int32).reshape(height, width)
 
 
-def gradient_noise_torch(width, height, seed, device="cuda", noise=24):
+def gradient_noise_torch(width, height, seed, device="cuda", noise=24, row0=0, rows=None):
     """gradient_noise() generated on the device with torch (bench.py fills a whole batch of distinct images this way): the same
     integer stream and float64 formulae; a device sin() that differs from numpy's in the last place can move a blue value that
-    sits exactly on a rounding boundary, nothing else.  Returns a flat int32 tensor of width*height ARGB pixels."""
+    sits exactly on a rounding boundary, nothing else.  Returns a flat int32 tensor of width*height ARGB pixels; with row0 / rows only
+    the rows [row0, row0 + rows) of that image (a rank's band of a tiled image)."""
     import torch
 
     def s64(v):
@@ -82,8 +83,10 @@ def gradient_noise_torch(width, height, seed, device="cuda", noise=24):
     def lsr(t, k):
         return (t >> k) & ((1 << (64 - k)) - 1)
 
-    n = width * height
-    i = torch.arange(n, dtype=torch.int64, device=device)
+    if rows is None:
+        rows = height - row0
+    n = width * rows
+    i = torch.arange(n, dtype=torch.int64, device=device) + row0 * width
     z = i + int(seed) + s64(0x9E3779B97F4A7C15)
     z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
     z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)

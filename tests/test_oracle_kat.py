@@ -75,6 +75,44 @@ def test_srgb_lab_identities(oracle):
                 assert (L.nqo_lab2rgb(al, l_, a_, b_) & 0xFFFFFFFF) == c
 
 
+def test_srgb_lab_published_secondaries_and_gray(oracle):
+    """More anchors for the restated ColorUtils.colorToLAB (D65, white 95.047 / 100 / 108.883): the published CIELAB values of
+    the sRGB secondaries and mid grey (Lindbloom / EasyRGB tables; androidx.core's ColorUtilsTest lists the same triples for
+    BLACK, WHITE, RED, GREEN, BLUE and CYAN to three decimals)."""
+    known = {0xFFFFFF00: (97.138, -21.556, 94.482),     # yellow
+             0xFF00FFFF: (91.117, -48.080, -14.138),    # cyan
+             0xFFFF00FF: (60.320, 98.254, -60.843),     # magenta
+             0xFF808080: (53.585, 0.003, -0.006)}       # mid grey: a*, b* are the white-point rounding residue, not 0
+    for c, (l, a, b) in known.items():
+        _, gl, ga, gb = oracle.rgb2lab(c)
+        assert abs(gl - l) < 1.5e-3 and abs(ga - a) < 1.5e-3 and abs(gb - b) < 1.5e-3, (hex(c), gl, ga, gb)
+    # L* is monotone in grey level and a*, b* stay at the residue
+    prev = -1.0
+    for v in range(256):
+        _, gl, ga, gb = oracle.rgb2lab(0xFF000000 | v << 16 | v << 8 | v)
+        assert gl > prev or v == 0
+        assert abs(ga) < 0.01 and abs(gb) < 0.02
+        prev = gl
+
+
+def test_java_random_published_sequences(oracle):
+    """java.util.Random is specified bit for bit (48-bit LCG, JLS / javadoc): the first outputs of new Random(0), new Random(42)
+    and new Random(1) as printed by any JVM."""
+    L = oracle.lib()
+    st = C.c_int64(0)
+    want = {0: [-1155484576, -723955400, 1033096058, -1690734402, -1557280266, 1327362106, -1930858313, 502539523, -1728529858, -938301587],
+            42: [-1170105035, 234785527, -1360544799, 205897768],
+            1: [-1155869325, 431529176, 1761283695, 1749940626]}
+    for seed, seq in want.items():
+        L.nqo_jrandom_seed(C.byref(st), seed)
+        assert [L.nqo_jrandom_next_int(C.byref(st)) for _ in seq] == seq, seed
+    # nextInt(bound) for a bound that is not a power of two = next(31) % bound with the rejection rule; bound 32767 is the one
+    # closestColorIndex draws (NQ/PnnLABQuantizer.java:467): consistent with nextInt() >>> 1 of the same stream
+    L.nqo_jrandom_seed(C.byref(st), 0)
+    a = [L.nqo_jrandom_next_int_bound(C.byref(st), 32767) for _ in range(6)]
+    assert a == [((v & 0xFFFFFFFF) >> 1) % 32767 for v in want[0][:6]]
+
+
 def test_java_random_known_answers(oracle):
     L = oracle.lib()
     st = C.c_int64(0)
