@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--concurrency", type=int, default=1,
                     help="host threads / HIP streams a step's batch is split over (measured: one call for the whole batch is best -- the "
                          "library then runs 128-thread merge workgroups, four per CU, and the per-pixel stages have the chip to themselves)")
+    ap.add_argument("--stagger", type=float, default=0.0,
+                    help="with --concurrency T > 1: host thread t starts its first batch t * stagger seconds late, so that the merge loops of "
+                         "one sub-batch (which leave most issue slots idle) run while another sub-batch is in its per-pixel stages")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,12 +172,14 @@ def main():
         o += share[t]
         st = torch.cuda.Stream()
         g[0]["q"].set_stream(st.cuda_stream)          # a batch runs on its first handle's stream
-        groups.append({"slots": g, "stream": st, "stages": {}, "n": 0, "pals": None, "err": None})
+        groups.append({"slots": g, "stream": st, "stages": {}, "n": 0, "pals": None, "err": None, "index": t})
 
     def run_group(gr, nsteps, record):
         # one host thread per sub-batch: the C ABI blocks only on its own stream (ctypes releases the GIL)
         try:
             sl = gr["slots"]
+            if args.stagger > 0 and gr["index"] > 0:
+                time.sleep(args.stagger * gr["index"])
             for _ in range(nsteps):
                 gr["pals"] = nq.convert_batch_device([s["q"] for s in sl], [s["in"].data_ptr() for s in sl], 256, True,
                                                      [s["out"].data_ptr() for s in sl], [s["idx"].data_ptr() for s in sl])

@@ -33,6 +33,13 @@ static inline int grid_for(int64_t n, int block, int cap = 256 * 8) {
     return (int) g;
 }
 
+// kernels that stage a K-entry palette (+ its Lab) in dynamic LDS: above 64 KB (LAB palettes beyond ~3700 entries, up to the
+// documented 8192) the launch needs the raised per-kernel limit
+template <typename Kern>
+static inline void allow_big_lds(Kern kernel, size_t bytes) {
+    if (bytes > 48 * 1024) (void) hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+}
+
 static inline CellLists to_lists(const ListsView& v) {
     CellLists l; l.closest = v.closest; l.closestCount = v.closestCount; l.nearest = v.nearest; l.nearestCount = v.nearestCount;
     return l;
@@ -47,9 +54,11 @@ void launch_build_lists(const DevParams& P, const int* d_palette, double wA, dou
                         unsigned char* d_nearestCount, hipStream_t s) {
     hipLaunchKernelGGL(build_closest_lists_kernel, dim3(65536 / 256), dim3(256), (size_t) P.K * sizeof(int), s, P, d_palette,
                        wA, wR, wG, wB, d_closest, d_closestCount);
-    if (nearest && P.kind == 1)
+    if (nearest && P.kind == 1) {
+        allow_big_lds(build_nearest_lists_kernel, palette_smem_bytes(P.kind, P.K));
         hipLaunchKernelGGL(build_nearest_lists_kernel, dim3(65536 / 256), dim3(256), palette_smem_bytes(P.kind, P.K), s, P, d_palette,
                            P.hasAlpha ? 1 : 0, d_box, d_nearest, d_nearestCount);
+    }
     else if (nearest)      // RGB: the nearestColorIndex weights are pa, pr, pg, pb themselves
         hipLaunchKernelGGL(build_nearest_rgb_lists_kernel, dim3(65536 / 256), dim3(256), (size_t) P.K * sizeof(int), s, P, d_palette,
                            P.K < 3 ? 1.0 : P.PA, P.K < 3 ? 1.0 : P.PR, P.K < 3 ? 1.0 : P.PG, P.K < 3 ? 1.0 : P.PB, d_nearest, d_nearestCount);
@@ -60,15 +69,18 @@ void launch_saliency(const DevParams& P, int salSubst, const int* d_pixels, int6
 }
 
 void launch_nearest_index(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_colors, int64_t M, short* d_out, hipStream_t s) {
+    allow_big_lds(nearest_index_kernel, palette_smem_bytes(P.kind, P.K));
     hipLaunchKernelGGL(nearest_index_kernel, dim3(grid_for(M, 256)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
                        P, d_palette, to_lists(lv), d_colors, (long long) M, d_out);
 }
 void launch_closest_tuple(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_colors, int64_t M, int* d_out4, hipStream_t s) {
+    allow_big_lds(closest_tuple_kernel, palette_smem_bytes(P.kind, P.K));
     hipLaunchKernelGGL(closest_tuple_kernel, dim3(grid_for(M, 256)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
                        P, d_palette, to_lists(lv), d_colors, (long long) M, d_out4);
 }
 void launch_lookup_only(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int64_t N,
                         unsigned short* d_index, int* d_argb, hipStream_t s) {
+    allow_big_lds(lookup_only_kernel, palette_smem_bytes(P.kind, P.K));
     hipLaunchKernelGGL(lookup_only_kernel, dim3(grid_for(N, 256, 256 * 16)), dim3(256), palette_smem_bytes(P.kind, P.K), s,
                        P, d_palette, to_lists(lv), d_pixels, (long long) N, d_index, d_argb);
 }
@@ -85,6 +97,7 @@ static void launch_gilbert_t(const DevParams& P, const GilbertConsts& G, const T
     const size_t base = palette_tables_smem_bytes(P.kind, P.K);
     const int tilepx = T.tile_w * T.tile_h;
     const bool stage = P.K <= 256 && tilepx <= 256 && !sequential;
+    allow_big_lds(gilbert_kernel<SORTED, DM, false>, base);
     if (stage)
         hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, true>), dim3(grid), dim3(block), base + (size_t) 64 * tilepx, s, P, G, T, L, d_pixels,
                            d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, d_tile_list);
@@ -113,6 +126,8 @@ void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView&
                       int y_origin, float weight, long long seed, int sequential, short* d_binCache, long long* d_rng_state,
                       unsigned short* d_index, int* d_argb, hipStream_t s) {
     const size_t smem = palette_smem_bytes(P.kind, P.K);
+    allow_big_lds(bluenoise_seq_kernel, smem);
+    allow_big_lds(bluenoise_kernel, palette_tables_smem_bytes(P.kind, P.K));
     if (sequential)
         hipLaunchKernelGGL(bluenoise_seq_kernel, dim3(1), dim3(64), smem, s, P, d_palette, to_lists(lv), d_pixels, width, height, weight,
                            d_binCache, d_rng_state, d_index, d_argb);

@@ -157,3 +157,29 @@ def test_indexed_png_of_a_gpu_result_decodes_to_the_oracle_index_map(nq, oracle,
     assert (plte == np.stack([(wp >> 16) & 0xFF, (wp >> 8) & 0xFF, wp & 0xFF], axis=1)).all()
     trns = np.frombuffer(chunks[b"tRNS"], np.uint8)
     assert len(trns) == len(wp) and (trns == ((wp >> 24) & 0xFF)).all() and (trns != 255).any()
+
+
+@pytest.mark.parametrize("kind,K", [(1, 4096), (1, 8192), (0, 8192)])
+def test_big_palettes_stage_through_lds_up_to_8192_entries(nq, oracle, kind, K):
+    """Palettes of thousands of entries (far beyond the reference's use, but inside the documented limit of the dither pass): the
+    LAB kind stages 16 bytes per entry + tables in LDS, above 64 KB from ~3700 entries on -- the launch must raise the kernel's
+    dynamic-LDS limit.  Dither and pure lookups against the oracle; 8193 entries are refused with NQ_ERR_UNSUPPORTED."""
+    img = synth.uniform_rgb(144, 128, 350 + K)
+    seed = 3
+    oq = oracle.OracleQuantizer(kind, img, seed=seed)
+    oq.prescan(K)
+    pal = oq.pnnquan(K)
+    assert len(pal) == K
+    params = _copy_params(oq.params, nq.Params)
+    want_argb, want_idx = oq.dither(pal, True, tile=(8, 8))
+    gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=TILED, seed=seed, tile=(8, 8))
+    gq.set_params(params)
+    got_argb, got_idx = gq.dither(pal, True)
+    assert (got_idx.astype(np.int32) == want_idx).all() and (got_argb == want_argb).all()
+    cols = (synth.splitmix64(K, 4000) & np.uint64(0xFFFFFF)).astype(np.uint32) | np.uint32(0xFF000000)
+    assert (gq.nearestColorIndex(pal, cols.view(np.int32)) == oq.nearest_index(pal, cols.view(np.int32))).all()
+    if K == 8192:
+        big = np.concatenate([pal, pal[:1]])
+        with pytest.raises(nq.NqError) as e:
+            gq.dither(big, True)
+        assert e.value.status == -3

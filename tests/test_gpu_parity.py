@@ -222,23 +222,59 @@ def test_lab_no_dither_convert_computes_distinct_colours(nq, oracle):
     assert (out.index.astype(np.int32) == want_idx).all() and (out.argb == want_argb).all()
 
 
-def test_tiled_deviation_from_sequential_reference_is_small(nq, oracle):
-    """PARALLEL_TILED vs the sequential reference semantics: per-pixel CIE76 deltaE against the source must not be
-    worse than the sequential oracle's by more than 10 %, and the two results stay close on average."""
-    img = synth.gradient_noise(128, 128, 61)
+def _np_lab(argb):
+    """CIELAB (D65) of ARGB pixels, float64 numpy -- for deltaE statistics only (the parity arithmetic lives in the oracle)."""
+    u = argb.view(np.uint32)
+    out = np.empty(argb.shape + (3,), np.float64)
+    lin = np.array([(c / 255.0) / 12.92 if c / 255.0 < 0.04045 else ((c / 255.0 + 0.055) / 1.055) ** 2.4 for c in range(256)])
+    r, g, b = lin[(u >> 16) & 0xFF], lin[(u >> 8) & 0xFF], lin[u & 0xFF]
+    xyz = [(0.4124 * r + 0.3576 * g + 0.1805 * b) / 0.95047, 0.2126 * r + 0.7152 * g + 0.0722 * b, (0.0193 * r + 0.1192 * g + 0.9505 * b) / 1.08883]
+    f = [np.where(t > 0.008856, np.cbrt(t), (903.3 * t + 16) / 116) for t in xyz]
+    out[..., 0] = np.maximum(0, 116 * f[1] - 16); out[..., 1] = 500 * (f[0] - f[1]); out[..., 2] = 200 * (f[1] - f[2])
+    return out
+
+
+def _box8(a):
+    h, w = a.shape[0] // 8 * 8, a.shape[1] // 8 * 8
+    return a[:h, :w].reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
+
+
+TILED_VS_SEQ = [("gradient_noise 256^2", lambda: synth.gradient_noise(256, 256, 61), None, 4),       # name, image, seed, automatic tile
+                ("uniform_rgb 224x160", lambda: synth.uniform_rgb(224, 160, 62), None, 4),
+                ("few bins 192^2", lambda: synth.few_colors(192, 192, 63, 2000), None, 64),          # sorted-by-yDiff queue: 64x64
+                ("bench image 4096^2", lambda: synth.gradient_noise(4096, 4096, 3), 3, 8)]
+
+
+@pytest.mark.parametrize("name,mk,seed,tile", TILED_VS_SEQ)
+def test_tiled_output_within_the_stated_deltaE_tolerance_of_the_sequential_reference(nq, oracle, name, mk, seed, tile):
+    """The north star's "LAB-space dithered output within a stated per-pixel deltaE tolerance": PARALLEL_TILED (GPU, automatic
+    tiles) against the SEQUENTIAL reference semantics (oracle, one curve over the image) on the same palette.  Two dithers of one
+    image differ pixel by pixel by construction (each pixel takes one of two neighbouring palette colours), so the tolerance is
+    stated per pixel against the SOURCE (CIE76: p50 / p99 of the tiled output no worse than the sequential output's by more than
+    5 % + 0.1, p99.9 by more than 10 % + 0.5, the single worst pixel by more than 50 %), on the 8x8 local means between the two outputs (p99 <= 20 % of the sequential
+    output's per-pixel p99, i.e. the patterns integrate to the same colours) and on the tile seams (mean Lab step across tile
+    boundaries <= 1.05 x the step inside the tiles).  Measured (tools/tiled_vs_sequential.py): e.g. bench image p50/p99/max
+    1.15/3.72/6.79 tiled vs 1.15/3.71/6.93 sequential, local means p99 0.31, seam ratio 1.008."""
+    img = mk()
+    s = 9 if seed is None else seed
+    H, W = img.shape
     oq, pal = _oracle_palette(oracle, 1, img, 256)
     params = _copy_params(oq.params, nq.Params)
-    oq.set_seed(9)
+    oq.set_seed(s)
     seq_argb, _ = oq.dither(pal, True)
-    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=9)
+    gq = nq.PnnLABQuantizer(img, mode=TILED, seed=s)
     gq.set_params(params)
     got_argb, _ = gq.dither(pal, True)
-    src = _lab_of(oracle, img)
-    e_seq = np.linalg.norm(_lab_of(oracle, seq_argb) - src, axis=1).mean()
-    e_gpu = np.linalg.norm(_lab_of(oracle, got_argb) - src, axis=1).mean()
-    assert e_gpu <= 1.10 * e_seq + 0.05, (e_gpu, e_seq)
-    d = np.linalg.norm(_lab_of(oracle, got_argb) - _lab_of(oracle, seq_argb), axis=1)
-    assert d.mean() < 6.0, d.mean()       # stated tolerance: mean CIE76 deltaE between tiled and sequential output
+    src, ls, lt = _np_lab(img), _np_lab(seq_argb), _np_lab(got_argb)
+    es, et = np.linalg.norm(ls - src, axis=2).ravel(), np.linalg.norm(lt - src, axis=2).ravel()
+    ps, pt = [np.percentile(es, q) for q in (50, 99, 99.9, 100)], [np.percentile(et, q) for q in (50, 99, 99.9, 100)]
+    assert pt[0] <= 1.05 * ps[0] + 0.1 and pt[1] <= 1.05 * ps[1] + 0.1 and pt[2] <= 1.10 * ps[2] + 0.5 and pt[3] <= 1.5 * ps[3], (name, ps, pt)
+    db = np.linalg.norm(_box8(ls) - _box8(lt), axis=2).ravel()
+    assert np.percentile(db, 99) <= 0.2 * ps[1] + 0.05, (name, float(np.percentile(db, 99)), ps)
+    d = np.linalg.norm(np.diff(lt, axis=1), axis=2)
+    cols = np.arange(d.shape[1])
+    seam = d[:, (cols % tile) == tile - 1].mean() / max(d[:, (cols % tile) == tile // 2 - 1].mean(), 1e-9)
+    assert seam <= 1.05, (name, seam)
 
 
 def test_full_size_properties_4096(nq):
