@@ -1,5 +1,8 @@
 """Randomised GPU-vs-oracle parity sweep (palette + scalars, tiled dither, lookups) over image kinds, sizes, K and flags.
-python tests/fuzz_parity.py [seconds] [seed] [big|seq]  -- prints every mismatch and a summary; exit code 1 on any mismatch."""
+python tests/fuzz_parity.py [seconds] [seed] [big|seq|fast]  -- prints every mismatch and a summary; exit code 1 on any mismatch.
+fast: the specialised dither kernel (csrc/nq_dither_fast.hip) -- LAB, 33 <= K <= 256, opaque or alpha-0 images, `weight` injected into
+both sides from (.0026, .0149) (the DITHER_MAX = 25 rung needs > 17 000 bins, i.e. large images, by itself), random tiles incl. odd ones,
+dither on / off; output, lookups and the tiles handed back are compared with the oracle and the generic kernel."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +13,7 @@ from nquant.android_amd import synth
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+FAST = len(sys.argv) > 3 and sys.argv[3] == "fast"
 SEQ = len(sys.argv) > 3 and sys.argv[3] == "seq"      # whole convert() in REFERENCE_SEQUENTIAL mode against the oracle's convert()      # 160..360 pixels a side (up to ~60k bins), palette + scalars only
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 Ks = [3, 4, 5, 6, 7, 8, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 1000]
@@ -33,6 +37,48 @@ while time.time() < t_end:
     rseed = int(rng.integers(0, 1 << 20))
     tag = "kind %d %dx%d gen %d seed %d K %d dither %d tile %d" % (kind, w, h, gen, seed, K, dither, tile[0])
     try:
+        if FAST:
+            K = int(rng.integers(33, 257))
+            w, h = int(rng.integers(24, 140)), int(rng.integers(24, 140))
+            g2 = int(rng.integers(0, 4))
+            img = synth.uniform_rgb(w, h, seed) if g2 == 0 else synth.gradient_noise(w, h, seed, noise=int(rng.integers(0, 64)))
+            if g2 == 3:
+                img = synth.with_alpha(img, seed, p_transparent=float(rng.random() * 0.05), p_semi=0.0)
+            tile = [(4, 4), (8, 8), (16, 16), (7, 5), (8, 4), (12, 12)][int(rng.integers(0, 6))]
+            weight = float(rng.uniform(0.0026, 0.0149))
+            tag = "FAST %dx%d gen %d seed %d K %d dither %d tile %s weight %.6f rseed %d" % (w, h, g2, seed, K, dither, tile, weight, rseed)
+            oq = oracle_lib.OracleQuantizer(1, img, seed=rseed)
+            oq.prescan(K)
+            pal = oq.pnnquan(K)
+            if len(pal) <= 32:
+                continue
+            op = oq.params
+            op.weight = weight; op.isNano = 1
+            oq.set_params(op)
+            gp = nq.Params()
+            for f, _ in nq.Params._fields_:
+                setattr(gp, f, getattr(op, f))
+            want_argb, want_idx = oq.dither(pal, dither, tile=tile)
+            n_cases += 1
+            for fast in (0, 1):          # (the lookups below then go through the specialised kernels)
+                gq = nq.PnnLABQuantizer(img, mode=nq.MODE_PARALLEL_TILED, seed=rseed, tile=tile)
+                gq.set_params(gp)
+                gq.set_option(2, fast)
+                got_argb, got_idx = gq.dither(pal, dither)
+                ran, back = gq.dither_path()
+                if ran != (fast if op.ratio >= 0 else 0):
+                    n_bad += 1; print("PATH MISMATCH: fast=%d ran=%d" % (fast, ran), tag, flush=True)
+                if (got_idx.astype(np.int32) != want_idx).any() or (got_argb != want_argb).any():
+                    n_bad += 1; print("FAST DITHER MISMATCH (fast=%d, handed back %d): %d px" % (fast, back, int((got_idx.astype(np.int32) != want_idx).sum())), tag, flush=True)
+            cols = (synth.splitmix64(seed, 8192) & np.uint64(0xFFFFFF)).astype(np.uint32) | np.uint32(0xFF000000)
+            cols = cols.view(np.int32)
+            if (gq.nearestColorIndex(pal, cols) != oq.nearest_index(pal, cols)).any():
+                n_bad += 1; print("FAST NEAREST MISMATCH:", tag, flush=True)
+            if (gq.closestTuple(pal, cols) != oq.closest_tuple(pal, cols)).any():
+                n_bad += 1; print("FAST CLOSEST MISMATCH:", tag, flush=True)
+            if n_cases % 25 == 0:
+                print("... %d cases, %d mismatches" % (n_cases, n_bad), flush=True)
+            continue
         if SEQ:
             Ks2 = K if rng.random() < 0.9 else int(rng.integers(1, 3))
             oq = oracle_lib.OracleQuantizer(kind, img, seed=rseed)
