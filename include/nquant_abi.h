@@ -103,6 +103,11 @@ int nq_set_option(nq_handle* h, int option, int value);
 int nq_get_dither_path(nq_handle* h, int32_t* out_fast, int32_t* out_failed_tiles);
 /* Diagnostics: length of every cell's candidate list of the last dither/lookup call (255 = full scan), 65536 bytes each. */
 int nq_get_list_counts(nq_handle* h, uint8_t* closest_counts, uint8_t* nearest_counts);
+/* Self-test hook of the branch-free CIEDE2000 evaluation inside find_nn (csrc/nq_device.h: ciede_terms_fast): for n pairs
+ * {L1, A1, B1, L2, A2, B2} returns, as float bit patterns, out9[9 i + 0..3] = deltaL', deltaC', deltaH', R_T of the fast pass,
+ * out9[9 i + 4..7] = the same from the literal functions, out9[9 i + 8] = 1 when the fast pass decided (else find_nn uses the
+ * literal values).  Wherever it decided the two quadruples must be identical. */
+int nq_selftest_ciede(nq_handle* h, const float* lab_pairs, int64_t n, uint32_t* out9);
 int nq_get_params(const nq_handle* h, nq_params* out);
 int nq_set_params(nq_handle* h, const nq_params* in);
 

@@ -840,6 +840,22 @@ int nq_set_option(nq_handle* h, int option, int value) {
     if (option == NQ_OPT_FAST_DITHER) { h->use_fast_dither = value != 0; return NQ_OK; }
     NQ_FAIL(h, NQ_ERR_INVALID, "unknown option %d", option);
 }
+int nq_selftest_ciede(nq_handle* h, const float* lab_pairs, int64_t n, uint32_t* out9) {
+    if (!h) return NQ_ERR_INVALID;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!lab_pairs || n <= 0 || !out9) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
+    float* d_in = nullptr; unsigned* d_out = nullptr;
+    NQ_HIP(h, hipMalloc((void**) &d_in, (size_t) n * 6 * sizeof(float)));
+    hipError_t e = hipMalloc((void**) &d_out, (size_t) n * 9 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, lab_pairs, (size_t) n * 6 * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) { launch_ciede_selftest(d_in, n, d_out, h->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out9, d_out, (size_t) n * 9 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void) hipFree(d_in); if (d_out) (void) hipFree(d_out);
+    if (e != hipSuccess) NQ_FAIL(h, NQ_ERR_HIP, "nq_selftest_ciede: %s", hipGetErrorString(e));
+    return NQ_OK;
+}
 int nq_get_dither_path(nq_handle* h, int32_t* out_fast, int32_t* out_failed_tiles) {
     if (!h) return NQ_ERR_INVALID;
     if (out_fast) *out_fast = h->last_dither_fast;

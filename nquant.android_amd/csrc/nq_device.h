@@ -234,6 +234,172 @@ __device__ __forceinline__ float R_T(double barCPrime, double barhPrime, float C
     return (float) (rt * C_prime_div * H_prime_div);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The four CIEDE2000 terms of one pair in ONE branch-free pass (the exact phase of find_nn is a single serial chain of these).
+// The literal functions above call the device library's pow / atan2 / sin / cos / exp: ~1500 instructions with internal branches.
+// Every result of theirs that matters is a FLOAT (deltaL', deltaC', deltaH', R_T are narrowed before they are used, :97,:117,:184,
+// :193) or a comparison of an angle with a float constant.  Here the same statement sequence is evaluated with bounded-argument
+// f64 kernels (Taylor / Cody-Waite, errors of a few ulp, all arguments are bounded: angles <= 9 pi, exponent <= 0) and each
+// narrowing is accepted only when the value lies farther from a float rounding boundary (resp. the angle farther from the
+// constant) than the accumulated error bound -- then EVERY implementation with ulp-level errors, the device library's and glibc's
+// included, narrows to the same float.  Otherwise ok = false and the caller runs the literal functions.
+// (selftest: nq_selftest_ciede, tests/test_gpu_boundary.py -- fast-or-fallback == literal, bit for bit, on millions of pairs.)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double nq_pow7(double x) { const double x2 = x * x, x3 = x2 * x, x4 = x2 * x2; return x4 * x3; }   // <= 2.5 ulp
+// e^a for a <= 0 (|error| < 1e-15 relative): Cody-Waite + degree-12 Taylor on |f| <= ln2 / 2
+__device__ __forceinline__ double nq_exp_neg(double a) {
+    const double n = rint(a * 1.4426950408889634);
+    double f = fma(n, -0.6931471803691238, a);
+    f = fma(n, -1.9082149292705877e-10, f);
+    double p = 2.08767569878681e-09;
+    p = fma(p, f, 2.505210838544172e-08); p = fma(p, f, 2.755731922398589e-07); p = fma(p, f, 2.7557319223985893e-06);
+    p = fma(p, f, 2.48015873015873e-05); p = fma(p, f, 0.0001984126984126984); p = fma(p, f, 0.001388888888888889);
+    p = fma(p, f, 0.008333333333333333); p = fma(p, f, 0.041666666666666664); p = fma(p, f, 0.16666666666666666);
+    p = fma(p, f, 0.5); p = fma(p, f, 1.0); p = fma(p, f, 1.0);
+    return ldexp(p, (int) fmax(n, -1080.0));
+}
+// sin and cos of |x| <= 64 (|error| < 4e-16 absolute): x = k pi/2 + r (fdlibm's two-part pi/2), Taylor to r^17 / r^18 on |r| <= pi/4
+__device__ __forceinline__ void nq_sincos(double x, double& sn, double& cs) {
+    const double k = rint(x * 0.6366197723675814);
+    double r = fma(k, -1.5707963267341256, x);
+    r = fma(k, -6.077100506506192e-11, r);
+    const double r2 = r * r;
+    double ps = 2.8114572543455206e-15;                 // 1/17!
+    ps = fma(ps, r2, -7.647163731819816e-13); ps = fma(ps, r2, 1.6059043836821613e-10); ps = fma(ps, r2, -2.505210838544172e-08);
+    ps = fma(ps, r2, 2.7557319223985893e-06); ps = fma(ps, r2, -0.0001984126984126984); ps = fma(ps, r2, 0.008333333333333333);
+    ps = fma(ps, r2, -0.16666666666666666);
+    const double sv = fma(r * r2, ps, r);
+    double pc = 1.5619206968586225e-16;                 // 1/18!
+    pc = fma(pc, r2, -4.779477332387385e-14); pc = fma(pc, r2, 1.1470745597729725e-11); pc = fma(pc, r2, -2.08767569878681e-09);
+    pc = fma(pc, r2, 2.755731922398589e-07); pc = fma(pc, r2, -2.48015873015873e-05); pc = fma(pc, r2, 0.001388888888888889);
+    pc = fma(pc, r2, -0.041666666666666664); pc = fma(pc, r2, 0.5);
+    const double cv = fma(-r2, pc, 1.0);
+    const int q = (int) k;
+    const bool odd = (q & 1) != 0;
+    double s0 = odd ? cv : sv, c0 = odd ? sv : cv;
+    if (q & 2) s0 = -s0;
+    if ((q + 1) & 2) c0 = -c0;
+    sn = s0; cs = c0;
+}
+// atan2(y, x), not both zero (|error| < 6e-16 absolute): t = min/max in [0, 1], atan(t) = atan(c) + atan((t - c) / (1 + t c)) with
+// c = round(4 t) / 4 (|argument| <= 1/8, Taylor to s^17), then the octant / quadrant / sign of IEEE atan2 (signed zeros included)
+__device__ __forceinline__ double nq_atan2(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const double t = mn / mx;
+    const double ci = rint(t * 4.0);
+    const double c = ci * 0.25;
+    const double sr = (t - c) / fma(t, c, 1.0);
+    const double s2 = sr * sr;
+    double p = 0.058823529411764705;                    // 1/17
+    p = fma(p, s2, -0.06666666666666667); p = fma(p, s2, 0.07692307692307693); p = fma(p, s2, -0.09090909090909091);
+    p = fma(p, s2, 0.1111111111111111); p = fma(p, s2, -0.14285714285714285); p = fma(p, s2, 0.2); p = fma(p, s2, -0.3333333333333333);
+    const double a = fma(sr * s2, p, sr);
+    const double base = ci < 0.5 ? 0.0 : ci < 1.5 ? 0.24497866312686414 : ci < 2.5 ? 0.4636476090008061 : ci < 3.5 ? 0.6435011087932844
+                                                                                                                   : 0.7853981633974483;
+    double r = base + a;
+    if (ay > ax) r = 1.5707963267948966 - r;
+    if (x < 0.0 || (x == 0.0 && __builtin_signbit(x))) r = 3.141592653589793 - r;
+    return copysign(r, y);
+}
+// do (v - m) and (v + m) narrow to the same float?
+__device__ __forceinline__ bool nq_narrow_safe(double v, double m) { return (float) (v - m) == (float) (v + m); }
+
+// deltaL', deltaC', deltaH', R_T of the pair (NQ/CIELABConvertor.java:91-98, :100-118, :120-185, :187-194); false = undecided
+__device__ __forceinline__ bool ciede_terms_fast(const Lab& lab1, const Lab& lab2, float& deltaL, float& deltaC, float& deltaH, float& rt_out) {
+    bool ok = true;
+    // :91-98 (sqrt is correctly rounded everywhere: identical values)
+    deltaL = L_prime_div_k_L_S_L(lab1, lab2);
+    // :100-118
+    const float pow25To7f = 6103515625.0f;
+    const float C1 = (float) sqrt((double) ((lab1.A * lab1.A) + (lab1.B * lab1.B)));
+    const float C2 = (float) sqrt((double) ((lab2.A * lab2.A) + (lab2.B * lab2.B)));
+    const float barC = (C1 + C2) / 2.0f;
+    const double barC7 = nq_pow7((double) barC);
+    const double ratioC = barC7 / (barC7 + (double) pow25To7f);
+    const double Gd = (double) 0.5f * (1 - sqrt(ratioC));
+    // Two evaluations whose barC^7 differ by <= 3.5 ulp feed quotients that differ by 3.5 ulp * (1 - ratio) relative, i.e. after the
+    // (correctly rounded) division and square root by at most one ulp of a number <= 1 each: |difference of Gd| <= 2.2e-16 +
+    // 2e-16 (1 - ratio).  The subtraction 1 - sqrt cancels absolutely, not relatively, so the margin is absolute.
+    ok = ok && nq_narrow_safe(Gd, 6e-16 + 1e-15 * (1.0 - ratioC));
+    const float G = (float) Gd;
+    const double a1Prime = (1.0 + G) * lab1.A, a2Prime = (1.0 + G) * lab2.A;
+    const double CPrime1 = sqrt((a1Prime * a1Prime) + (double) (lab1.B * lab1.B));
+    const double CPrime2 = sqrt((a2Prime * a2Prime) + (double) (lab2.B * lab2.B));
+    {
+        const float deltaCPrime = (float) CPrime2 - (float) CPrime1;
+        const float barCPrimeF = ((float) CPrime1 + (float) CPrime2) / 2.0f;
+        const float S_C = 1 + (0.045f * barCPrimeF);
+        deltaC = deltaCPrime / S_C;
+    }
+    // :120-185
+    const float deg360InRad = deg2Rad(360.0), deg180InRad = deg2Rad(180.0);
+    const double CPrimeProduct = CPrime1 * CPrime2;
+    double hPrime1 = 0.0, hPrime2 = 0.0;
+    if (!((double) lab1.B == 0.0 && a1Prime == 0.0)) { hPrime1 = nq_atan2((double) lab1.B, a1Prime); if (hPrime1 < 0) hPrime1 += deg360InRad; }
+    if (!((double) lab2.B == 0.0 && a2Prime == 0.0)) { hPrime2 = nq_atan2((double) lab2.B, a2Prime); if (hPrime2 < 0) hPrime2 += deg360InRad; }
+    const double AERR = 4e-15;                           // bound on the error of an angle / of a sum or difference of two
+    double deltahPrime = 0;
+    if (CPrimeProduct != 0.0) {
+        deltahPrime = hPrime2 - hPrime1;
+        ok = ok && fabs(fabs(deltahPrime) - (double) deg180InRad) > 16 * AERR;      // (also decides :166 below)
+        if (deltahPrime < -deg180InRad) deltahPrime += deg360InRad;
+        else if (deltahPrime > deg180InRad) deltahPrime -= deg360InRad;
+    }
+    double sh, ch_unused;
+    nq_sincos(deltahPrime / 2.0, sh, ch_unused);
+    const double deltaHPrime = 2.0 * sqrt(CPrimeProduct) * sh;
+    const double hPrimeSum = hPrime1 + hPrime2;
+    double barhPrime;
+    if (CPrimeProduct == 0.0) barhPrime = hPrimeSum;
+    else {
+        if (fabs(hPrime1 - hPrime2) <= deg180InRad) barhPrime = hPrimeSum / 2.0;
+        else {
+            ok = ok && fabs(hPrimeSum - (double) deg360InRad) > 16 * AERR;
+            if (hPrimeSum < deg360InRad) barhPrime = (hPrimeSum + deg360InRad) / 2.0;
+            else barhPrime = (hPrimeSum - deg360InRad) / 2.0;
+        }
+    }
+    const double barCPrime = (CPrime1 + CPrime2) / 2.0;
+    const double bh = barhPrime;
+    double s1, c1, s2_, c2, s3, c3, s4, c4;
+    nq_sincos(bh - deg2Rad(30.0), s1, c1);
+    nq_sincos(2.0 * bh, s2_, c2);
+    nq_sincos((3.0 * bh) + deg2Rad(6.0), s3, c3);
+    nq_sincos((4.0 * bh) - deg2Rad(63.0), s4, c4);
+    const double T = 1.0 - (0.17 * c1) + (0.24 * c2) + (0.32 * c3) - (0.20 * c4);
+    const double S_H = 1 + ((double) 0.015f * barCPrime * T);
+    const double Hd = deltaHPrime / S_H;
+    // error of Hd: sin(dh/2) carries the absolute angle error AERR (relative AERR / |dh/2| when the hues nearly coincide), T an
+    // absolute 2e-15 (four cosines of arguments with error <= 4 AERR), S_H <= 0.015 * 182 * that: relative 6e-15
+    {
+        const double rel = 1e-13 + (deltahPrime != 0.0 ? 4 * AERR / fabs(deltahPrime) : 0.0);
+        ok = ok && rel < 1e-9 && nq_narrow_safe(Hd, fabs(Hd) * rel);
+    }
+    deltaH = (float) Hd;
+    // :187-194
+    const double zz = (barhPrime - deg2Rad(275.0)) / deg2Rad(25.0);
+    const double deltaTheta = deg2Rad(30.0) * nq_exp_neg(-(zz * zz));
+    const double bc7 = nq_pow7(barCPrime);
+    const double R_C = 2.0 * sqrt(bc7 / (bc7 + 6103515625.0));
+    double s5, c5;
+    nq_sincos(2.0 * deltaTheta, s5, c5);
+    const double rtv = ((-s5) * R_C) * deltaC * deltaH;
+    // error of rtv: the exponent zz^2 <= 8100 carries 2 |zz| AERR / 0.436 absolute -> relative 6e-13 on exp, the rest is ulps
+    ok = ok && nq_narrow_safe(rtv, fabs(rtv) * 2e-12);
+    rt_out = (float) rtv;
+    (void) ch_unused; (void) s1; (void) s2_; (void) s3; (void) s4; (void) c5;
+    return ok;
+}
+// the same four floats by the literal functions (device library)
+__device__ __forceinline__ void ciede_terms_literal(const Lab& lab1, const Lab& lab2, float& deltaL, float& deltaC, float& deltaH, float& rt_out) {
+    deltaL = L_prime_div_k_L_S_L(lab1, lab2);
+    double a1Prime, a2Prime, CPrime1, CPrime2, barCPrime, barhPrime;
+    deltaC = C_prime_div_k_L_S_L(lab1, lab2, a1Prime, a2Prime, CPrime1, CPrime2);
+    deltaH = H_prime_div_k_L_S_L(lab1, lab2, a1Prime, a2Prime, CPrime1, CPrime2, barCPrime, barhPrime);
+    rt_out = R_T(barCPrime, barhPrime, deltaC, deltaH);
+}
+
 // :215-227 / :229-238
 __device__ __forceinline__ double color2Y(int c) {
     double sr = g_tab.gamma[c_red(c)], sg = g_tab.gamma[c_green(c)], sb = g_tab.gamma[c_blue(c)];

@@ -122,6 +122,7 @@ void launch_distinct(const int* d_pixels, int64_t n, int transparentColor, unsig
 // colours present in a band: opaque ones mark d_bytes[rgb] (2^24 bytes, NOT cleared here: bands accumulate), the others enter the set
 void launch_color_presence(const int* d_pixels, int64_t n, int transparentColor, unsigned char* d_bytes, unsigned* d_set, unsigned slots,
                            unsigned* d_counters, hipStream_t s);
+void launch_ciede_selftest(const float* d_pairs /* n x 6 */, int64_t n, unsigned* d_out /* n x 9 */, hipStream_t s);
 void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s);
 void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams& hp, const SortWorkspace& ws,
                       double* d_hist, hipStream_t s);

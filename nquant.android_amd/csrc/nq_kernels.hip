@@ -175,6 +175,9 @@ void launch_color_presence(const int* d_pixels, int64_t n, int transparentColor,
     hipLaunchKernelGGL(color_presence_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, transparentColor,
                        d_bytes, d_set, slots, d_counters);
 }
+void launch_ciede_selftest(const float* d_pairs, int64_t n, unsigned* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(ciede_selftest_kernel, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, d_pairs, (long long) n, d_out);
+}
 void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s) {
     (void) hipMemsetAsync(d_scan3, 0xFF, 2 * sizeof(long long), s);      // {-1, -1}
     (void) hipMemsetAsync(d_scan3 + 2, 0, sizeof(long long), s);

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "nq_set_params", "nq_convert", "nq_convert_device", "nq_convert_batch_device", "nq_convert_batch", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
     "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_band_distinct_device", "nq_set_distinct", "nq_get_stage_ms", "nq_get_merge_stats",
-    "nq_get_dither_path", "nq_set_band", "nq_band_color_presence_device", "nq_gilbert_dither", "nq_bluenoise_dither",
+    "nq_get_dither_path", "nq_set_band", "nq_band_color_presence_device", "nq_gilbert_dither", "nq_bluenoise_dither", "nq_selftest_ciede",
 ]
 OPT_CELL_LISTS, OPT_FAST_DITHER = 1, 2
 
@@ -119,6 +119,7 @@ def load_library():
     L.nq_get_merge_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.nq_get_dither_path.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.nq_set_band.argtypes = [vp, i32, i32]
+    L.nq_selftest_ciede.argtypes = [vp, vp, i64, vp]
     L.nq_gilbert_dither.argtypes = [vp, i32, i32, vp, vp, i32, vp, C.c_double, i32, i64, i32, vp, vp]
     L.nq_bluenoise_dither.argtypes = [vp, i32, i32, vp, vp, i32, vp, C.c_float, i64, i32, vp]
     L.nq_band_color_presence_device.argtypes = [vp, vp, i64, vp, i32, C.POINTER(C.c_int64), vp]
@@ -289,6 +290,13 @@ class PnnQuantizer:
                                                 io.ctypes.data, float(weight), int(self.seed if seed is None else seed),
                                                 int(self.mode if mode is None else mode), idx.ctypes.data))
         return io.reshape(self.height, self.width), idx.reshape(self.height, self.width)
+
+    def selftest_ciede(self, lab_pairs):
+        """(n, 6) float32 {L1,A1,B1,L2,A2,B2} -> (n, 4) fast floats, (n, 4) literal floats (as uint32 bit patterns), (n,) decided flags."""
+        a = np.ascontiguousarray(lab_pairs, np.float32).reshape(-1, 6)
+        out = np.zeros((a.shape[0], 9), np.uint32)
+        self._check(self._L.nq_selftest_ciede(self._h, a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out[:, 0:4], out[:, 4:8], out[:, 8]
 
     def nearestColorIndex(self, palette, colors):
         """short nearestColorIndex(palette, c, pos) on a cache miss, vectorised over `colors`."""

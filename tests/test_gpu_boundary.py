@@ -183,3 +183,40 @@ def test_big_palettes_stage_through_lds_up_to_8192_entries(nq, oracle, kind, K):
         with pytest.raises(nq.NqError) as e:
             gq.dither(big, True)
         assert e.value.status == -3
+
+
+def test_branch_free_ciede2000_equals_the_literal_functions(nq):
+    """find_nn's exact phase evaluates deltaL', deltaC', deltaH', R_T in one branch-free pass (csrc/nq_device.h: ciede_terms_fast) and
+    falls back to the literal functions (device-library pow / atan2 / sin / cos / exp) wherever a float narrowing or an angle
+    comparison is too close to call.  Wherever the fast pass decides, its four floats must equal the literal ones bit for bit:
+    3 million random pairs (uniform Lab, near-grey, near-equal hue, antipodal hue, equal colours, the Sharma table) -- and it must
+    decide almost always, or it would not be worth having."""
+    rng = np.random.default_rng(2024)
+    n = 500_000
+    def lab(n, chroma=128.0):
+        return np.stack([rng.uniform(0, 100, n), rng.uniform(-chroma, chroma, n), rng.uniform(-chroma, chroma, n)], axis=1)
+    sets = [np.concatenate([lab(n), lab(n)], axis=1),                                   # anything with anything
+            np.concatenate([lab(n, 2.0), lab(n, 2.0)], axis=1),                         # near the grey axis
+            None, None, None, None]
+    a = lab(n)
+    sets[2] = np.concatenate([a, a + rng.normal(0, 0.3, a.shape)], axis=1)             # close neighbours (what find_nn mostly sees)
+    ang = rng.uniform(0, 2 * np.pi, n); r1 = rng.uniform(1, 120, n); r2 = rng.uniform(1, 120, n)
+    sets[3] = np.stack([rng.uniform(0, 100, n), r1 * np.cos(ang), r1 * np.sin(ang),
+                        rng.uniform(0, 100, n), -r2 * np.cos(ang), -r2 * np.sin(ang)], axis=1)     # antipodal hues (the 180 degree branch)
+    d = rng.normal(0, 1e-6, n)
+    sets[4] = np.stack([rng.uniform(0, 100, n), r1 * np.cos(ang), r1 * np.sin(ang),
+                        rng.uniform(0, 100, n), r2 * np.cos(ang + d), r2 * np.sin(ang + d)], axis=1)  # nearly equal hues
+    b = lab(n)
+    b[:, 2] = 0.0                                                                        # B == 0 (atan2(+-0, x))
+    sets[5] = np.concatenate([b, lab(n)], axis=1)
+    q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32))
+    decided_total = 0
+    for k, s in enumerate(sets):
+        fast, lit, ok = q.selftest_ciede(s.astype(np.float32))
+        dec = ok == 1
+        bad = (fast[dec] != lit[dec]).any(axis=1)
+        assert not bad.any(), "set %d: %d of %d decided pairs differ, first %s" % (k, int(bad.sum()), int(dec.sum()), s[dec][bad][:1])
+        decided_total += int(dec.sum())
+        if k != 4:                          # hues 1e-6 rad apart: the sine of the half difference loses all relative accuracy -> always literal
+            assert dec.mean() > 0.95, (k, float(dec.mean()))
+    assert decided_total > 0.8 * n * (len(sets) - 1)
