@@ -148,8 +148,8 @@ def main():
         Bn = max(1, fit)
     T = max(1, min(args.concurrency, Bn))
     tile = args.tile
-    if tile <= 0:      # the library's automatic rule (nq_set_tile): largest of 16, 8, 4 with >= 131072 tiles
-        tile = next((c for c in (16, 8) if ((W + c - 1) // c) * ((H + c - 1) // c) >= 131072), 4)
+    if tile <= 0:      # the library's automatic rule (nq_set_tile): 8x8 with >= 131072 tiles, else 4x4
+        tile = 8 if ((W + 7) // 8) * ((H + 7) // 8) >= 131072 else 4
 
     # the batch: Bn distinct images (seed 3 + rank * Bn + slot), inputs and outputs resident in HBM
     slots = []

@@ -80,8 +80,8 @@ const char* nq_last_error(const nq_handle* h);   /* h may be NULL: last error of
 int nq_abi_version(void);
 /* All work of the handle is enqueued on this hipStream_t (NULL = the default stream). */
 int nq_set_stream(nq_handle* h, void* hip_stream);
-/* Tile of the PARALLEL_TILED decomposition; <= 0 (default) = automatic: the largest of 16x16, 8x8, 4x4 that gives the GPU
- * at least 131072 independent chains (4x4 below that); 64x64 when the GilbertCurve constructor selects the sorted-by-yDiff
+/* Tile of the PARALLEL_TILED decomposition; <= 0 (default) = automatic: 8x8 when that gives the GPU at least 131072
+ * independent chains (images from about 2900^2 pixels), 4x4 below that; 64x64 when the GilbertCurve constructor selects the sorted-by-yDiff
  * queue (K > 128 && weight >= .02: its start-up transient at every chain start costs quality with short chains). */
 int nq_set_tile(nq_handle* h, int tile_w, int tile_h);
 /* One image tiled over GPUs: this handle's following nq_dither[_device] calls treat their pixel buffer as the rows

@@ -661,12 +661,14 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     if (sequential) { T.tile_w = width; T.tile_h = height; }
     else if (h->tile_w > 0 && h->tile_h > 0) { T.tile_w = std::min(h->tile_w, width); T.tile_h = std::min(h->tile_h, height); }
     else {
-        // automatic: the largest square tile of 16, 8, 4 that still yields >= 2 wavefronts of chains per SIMD (131072 chains);
-        // the tile size does not change the measured dither quality, it only sets how many chains run in parallel
+        // automatic: 8x8 when that yields >= 2 wavefronts of chains per SIMD (131072 chains), else 4x4.  The tile size does not change
+        // the measured dither quality, it sets how many chains run in parallel and how much LDS a chain's staged indices
+        // take: 16x16 (the round-1 choice for images beyond 5793^2) ran the 16384^2 pass in 22.7 ms, 8x8 in 12.5 ms
         int tsz = 4;
-        for (int cand : {16, 8}) {
+        {
+            const int cand = 8;
             const int64_t tiles = (int64_t) ((width + cand - 1) / cand) * ((rule_h + cand - 1) / cand);
-            if (tiles >= 131072) { tsz = cand; break; }
+            if (tiles >= 131072) tsz = cand;
         }
         // sorted-by-yDiff queue (few-bin images: K > 128 && weight >= .02): the queue GROWS 1 -> 3 -> 7 -> 15 from empty at the start
         // of every chain (NQ/GilbertCurve.java:231-234) and the first pixels of a chain occasionally land far off (measured with the

@@ -37,10 +37,9 @@ def _oracle_palette(oracle, kind, img, K):
 
 
 def auto_tile(w, h):
-    """The automatic rule of nq_dither_device (csrc/nq_abi.cpp: the largest of 16, 8, 4 that yields >= 131072 chains, else 4)."""
-    for cand in (16, 8):
-        if ((w + cand - 1) // cand) * ((h + cand - 1) // cand) >= 131072:
-            return (min(cand, w), min(cand, h))
+    """The automatic rule of nq_dither_device (csrc/nq_abi.cpp): 8x8 when that yields >= 131072 chains, else 4x4 (non-sorted queue)."""
+    if ((w + 7) // 8) * ((h + 7) // 8) >= 131072:
+        return (min(8, w), min(8, h))
     return (min(4, w), min(4, h))
 
 
