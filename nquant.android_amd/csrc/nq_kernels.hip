@@ -52,7 +52,7 @@ void launch_cell_lab_box(float* d_box, hipStream_t s) {
 void launch_build_lists(const DevParams& P, const int* d_palette, double wA, double wR, double wG, double wB, bool nearest,
                         const float* d_box, unsigned char* d_closest, unsigned char* d_closestCount, unsigned char* d_nearest,
                         unsigned char* d_nearestCount, hipStream_t s) {
-    hipLaunchKernelGGL(build_closest_lists_kernel, dim3(65536 / 256), dim3(256), (size_t) P.K * sizeof(int), s, P, d_palette,
+    hipLaunchKernelGGL(build_closest_lists_kernel, dim3(65536 / 256), dim3(256), 0, s, P, d_palette,
                        wA, wR, wG, wB, d_closest, d_closestCount);
     if (nearest && P.kind == 1) {
         allow_big_lds(build_nearest_lists_kernel, palette_smem_bytes(P.kind, P.K));
