@@ -752,7 +752,10 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         const double delta = sqr(K) / (double) distinct;
         blueWeight = delta > 0.023 ? 1.0f : (float) (37.013 * delta + 0.906);
     }
-    if (post)
+    if (post && !sequential && h->use_fast_dither && fast_lookup_eligible(P, lv))
+        launch_fast_bluenoise(P, lv, h->d_palette.p, packed_lists(h), (const int*) d_argb, width, height, T.y_origin, blueWeight, (long long) seed,
+                              d_out_index, (int*) d_out_argb, h->stream);
+    else if (post)
         launch_bluenoise(P, h->d_palette.p, lv, (const int*) d_argb, width, height, T.y_origin, blueWeight, (long long) seed, sequential ? 1 : 0,
                          h->d_bincache.p, h->d_scalars.p, d_out_index, (int*) d_out_argb, h->stream);
     rec(h, 7);

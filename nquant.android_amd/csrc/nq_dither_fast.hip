@@ -111,12 +111,14 @@ __host__ __device__ __forceinline__ int fast_stride_bytes(int tilepx) {
 // v = 1 - 2t/(1 + t), t = exp(-2|x|): Cody-Waite reduction, degree-12 Taylor polynomial on |f| <= ln2/2 (truncation 1.7e-16),
 // two Newton steps on v_rcp_f64; |v - tanh| < 1e-15.  The float nearest to v is the float nearest to tanh unless a rounding
 // boundary lies within that error: then (v - 1e-14) and (v + 1e-14) round differently and the library decides (3e-7 of all calls).
+__device__ __attribute__((noinline)) float tanh_library(double ax) { return (float) tanh(ax); }      // cold: 3e-7 of the calls
+__device__ __attribute__((noinline)) float normal_distribution_cold(float x, float peak) { return normalDistribution(x, peak); }
 __device__ __forceinline__ float tanh_to_float(float xf) {
     const double x = (double) xf;
     const double ax = fabs(x);
     float r;
     if (ax >= 9.2) r = 1.0f;                     // 1 - tanh < 2 exp(-18.4) = 2.1e-8 < 2^-25: rounds to 1.0f
-    else if (ax < 0.5) r = (float) tanh(ax);     // not reached by the limiter (|e| >= ditherMax); kept for completeness
+    else if (ax < 0.5) r = tanh_library(ax);     // not reached by the limiter (|e| >= ditherMax); kept for completeness
     else {
         const double z = -2.0 * ax;
         const double n = rint(z * 1.4426950408889634);
@@ -143,7 +145,7 @@ __device__ __forceinline__ float tanh_to_float(float xf) {
         const double v = 1.0 - 2.0 * t * rc;
         const float lo = (float) (v - 1e-14), hi = (float) (v + 1e-14);
         r = lo;
-        if (lo != hi) r = (float) tanh(ax);
+        if (lo != hi) r = tanh_library(ax);
     }
     return x < 0 ? -r : r;
 }
@@ -210,7 +212,7 @@ __device__ __forceinline__ void lab32_of(int c, const float* __restrict__ g32, f
 }
 
 // exact nearestColorIndex over a candidate list (the list branch of nearest_lab, nq_device.h): f64 reference arithmetic
-__device__ __forceinline__ int fast_nearest_exact(const FastLds& S, int c, uint4 list, const uint4* cont, int n, int kfirst) {
+__device__ __attribute__((noinline)) int fast_nearest_exact(const FastLds& S, int c, uint4 list, const uint4* cont, int n, int kfirst) {
     const Lab lab1 = RGB2LAB_fast(c, S.gamma);
     double mindist = 2147483647.0;
     int k = kfirst;
@@ -296,6 +298,30 @@ __device__ __forceinline__ int fast_nearest(const FastLds& S, const FastLookup& 
     return k1;
 }
 
+// which of the two closest candidates (NQ/PnnLABQuantizer.java:465-468): 0 when closest[2] == 0 or
+// random.nextInt(32767) % (closest[3] + closest[2]) <= closest[3], else 1; draws from `rng` exactly when the reference does
+__device__ __forceinline__ int fast_closest_pick(const FastClosest& t, long long& rng) {
+    if (t.e0 == 0) return 0;
+    // random.nextInt(32767): next(31), then the rejection loop of the non-power-of-two bound (taken with probability 1e-9)
+    int r;
+    for (;;) {
+        const int uu = jr_next(rng, 31);
+        int v = (uu >> 15) + (uu & 32767);                  // 32768 == 1 (mod 32767)
+        v = (v >> 15) + (v & 32767);
+        r = v >= 32767 ? v - 32767 : v;
+        if ((int) ((unsigned) (uu - r) + 32766u) >= 0) break;
+    }
+    const int dsum = (int) ((unsigned) t.e1 + (unsigned) t.e0);
+    int rem = r;                                            // dsum < 0 (wrapped) or dsum > r: r % dsum == r
+    if (dsum > 0 && dsum <= r) {
+        // r < 2^15: the float quotient is within 0.01 of the true one
+        int qq = (int) ((float) r * __builtin_amdgcn_rcpf((float) dsum));
+        rem = r - qq * dsum;
+        if (rem < 0) rem += dsum; else if (rem >= dsum) rem -= dsum;
+    }
+    return rem <= t.e1 ? 0 : 1;
+}
+
 // Y_Diff(c1, c2) > thr (gt) or < thr (!gt), NQ/CIELABConvertor.java:215-227.  float32 first: each luminance is within 4e-7 of
 // its f64 value (table entries 6e-8 relative, three products, two sums, Y <= 1), the difference times 100 within 1e-4.
 __device__ __forceinline__ bool fast_ydiff_cmp(const FastLds& S, int c1, int c2, double thr, bool gt) {
@@ -321,7 +347,7 @@ __device__ __forceinline__ int fast_dither_color(const FastLds& S, const Gilbert
     if (2 * acceptedDiff > 100 || fast_ydiff_cmp(S, pixel, c2, (double) (2 * acceptedDiff), false)) {       // Y_Diff <= 100 always
         float kappa;
         if (K > 64) kappa = sal < .6f ? beta * .15f / sal : beta * .4f / sal;
-        else if (weight < .005) kappa = beta * normalDistribution(sal, .5f) + beta;
+        else if (weight < .005) kappa = beta * normal_distribution_cold(sal, .5f) + beta;
         else kappa = beta * .5f / sal;
         c2 = blue_diffuse_t(pixel, qcur, kappa, strength, x, y, S.blue);
     }
@@ -342,7 +368,7 @@ __device__ __forceinline__ int fast_dither_color(const FastLds& S, const Gilbert
                     else peak = weight < .0025 ? 1.82f : 2.0f;
                 }
             }
-            if (peak > 0.f) kappa = beta * normalDistribution(sal, peak);
+            if (peak > 0.f) kappa = beta * normal_distribution_cold(sal, peak);
             c2 = blue_diffuse_t(c1, qcur, kappa, strength, x, y, S.blue);
         }
         else c2 = c_in;
@@ -489,29 +515,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                 if (ncl == 255 || nnr == 255) failed = true;
                 const int n1 = (ncl == 255 || NQ_KO(16)) ? 0 : ncl, n2 = nnr == 255 ? 0 : nnr;
                 const FastClosest t = fast_closest_tuple(S, X, c, la, n1, cell);
-                // :465-468
-                int idx = 1;
-                if (t.e0 == 0) idx = 0;
-                else {
-                    // random.nextInt(32767): next(31), then the rejection loop of the non-power-of-two bound (taken with probability 1e-9)
-                    int r;
-                    for (;;) {
-                        const int uu = jr_next(rng, 31);
-                        int v = (uu >> 15) + (uu & 32767);                  // 32768 == 1 (mod 32767)
-                        v = (v >> 15) + (v & 32767);
-                        r = v >= 32767 ? v - 32767 : v;
-                        if ((int) ((unsigned) (uu - r) + 32766u) >= 0) break;
-                    }
-                    const int dsum = (int) ((unsigned) t.e1 + (unsigned) t.e0);
-                    int rem = r;                                            // dsum < 0 (wrapped) or dsum > r: r % dsum == r
-                    if (dsum > 0 && dsum <= r) {
-                        // r < 2^15: the float quotient is within 0.01 of the true one
-                        int qq = (int) ((float) r * __builtin_amdgcn_rcpf((float) dsum));
-                        rem = r - qq * dsum;
-                        if (rem < 0) rem += dsum; else if (rem >= dsum) rem -= dsum;
-                    }
-                    if (rem <= t.e1) idx = 0;
-                }
+                const int idx = fast_closest_pick(t, rng);              // :465-468
                 const int ci = idx ? t.c1 : t.c0, ei = idx ? t.e1 : t.e0;
                 qidx = ci;
                 if ((ei >= K || ci == 0 || c_alpha(S.argb[ci]) < c_alpha(c)) && !NQ_KO(2)) {
@@ -671,6 +675,44 @@ __global__ void __launch_bounds__(256) fast_lookup_only_kernel(DevParams P, Cell
         if (out_argb) out_argb[i] = T.S.argb[k];
     }
 }
+// BlueNoise.dither (NQ/BlueNoise.java:207-222), parallel form (one Random(mix64((seed ^ tag) + i)) per pixel, as bluenoise_kernel of
+// nq_dither.inc and the oracle's tiled restatement): the lookup is closestColorIndex through the float32-filtered functions above
+__global__ void __launch_bounds__(256) fast_bluenoise_kernel(DevParams P, CellLists lists, FastArgs F, const int* __restrict__ g_palette,
+                                                             const int* __restrict__ pixels, int width, int height, int y_origin, float weight,
+                                                             long long seed, unsigned short* __restrict__ io_index, int* __restrict__ out_argb) {
+    __shared__ __align__(16) signed char s_blue[4096];
+    for (int i = threadIdx.x; i < 1024; i += 256) ((int*) s_blue)[i] = ((const int*) g_tab.blue)[i];
+    FastLookupLds T = fast_stage_lookup(P, g_palette);          // ends with a barrier
+    T.S.blue = s_blue;
+    const FastLookup X = fast_lookup_ctx(P, F);
+    const int K = P.K;
+    const long long N = (long long) width * height;
+    const float strength = 1 / 3.0f;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long) gridDim.x * blockDim.x) {
+        const int y = (int) (i / width), x = (int) (i - (long long) y * width);
+        const long long gi = i + (long long) y_origin * width;
+        const int pixel = pixels[i];
+        const int c = blue_diffuse_t(pixel, T.S.argb[io_index[i]], weight, strength, x, y + y_origin, s_blue);
+        long long rng = jr_seed((long long) mix64(((unsigned long long) seed ^ 0xB10E5EEDULL) + (unsigned long long) gi));
+        int k;
+        if (c_alpha(c) <= 0xF) k = nearest_lab(P, T.pal, c, &lists);                  // closestColorIndex :408-409
+        else {
+            const int cell = cell_of(c);
+            const uint4 la = X.packed[2 * cell], na = X.packed[2 * cell + 1];
+            const int ncl = (int) (la.w >> 24), nnr = (int) (na.w >> 24);
+            FastClosest t;
+            if (ncl != 255) t = fast_closest_tuple(T.S, X, c, la, ncl, cell);
+            else { int cl[4]; closest_tuple_lab(P, T.pal, c, cl, &lists); t.c0 = cl[0]; t.c1 = cl[1]; t.e0 = cl[2]; t.e1 = cl[3]; }
+            const int idx = fast_closest_pick(t, rng);
+            const int ci = idx ? t.c1 : t.c0, ei = idx ? t.e1 : t.e0;
+            k = ci;
+            if (ei >= K || ci == 0 || c_alpha(T.S.argb[ci]) < c_alpha(c))
+                k = nnr != 255 ? fast_nearest(T.S, X, c, na, nnr, cell) : nearest_lab(P, T.pal, c, &lists);
+        }
+        io_index[i] = (unsigned short) k;
+        out_argb[i] = T.S.argb[k];
+    }
+}
 __global__ void __launch_bounds__(256) fast_closest_tuple_kernel(DevParams P, CellLists lists, FastArgs F, const int* __restrict__ g_palette,
                                                                  const int* __restrict__ colors, long long M, int* __restrict__ out4) {
     const FastLookupLds T = fast_stage_lookup(P, g_palette);
@@ -692,7 +734,6 @@ __global__ void __launch_bounds__(256) fast_closest_tuple_kernel(DevParams P, Ce
         reinterpret_cast<int4*>(out4)[i] = make_int4(closest[0], closest[1], closest[2], closest[3]);
     }
 }
-
 } // namespace nq
 
 namespace nq {
@@ -784,6 +825,12 @@ void launch_fast_lookup_only(const DevParams& P, const ListsView& lv, const int*
     const FastArgs F = fast_args(P, lv, d_packed, s);
     hipLaunchKernelGGL(fast_lookup_only_kernel, dim3(fast_grid(N)), dim3(256), 0, s, P, to_lists_fast(lv), F, d_palette, d_pixels, (long long) N,
                        d_index, d_argb);
+}
+void launch_fast_bluenoise(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_pixels, int width, int height,
+                           int y_origin, float weight, long long seed, unsigned short* d_index, int* d_argb, hipStream_t s) {
+    const FastArgs F = fast_args(P, lv, d_packed, s);
+    hipLaunchKernelGGL(fast_bluenoise_kernel, dim3(fast_grid((int64_t) width * height)), dim3(256), 0, s, P, to_lists_fast(lv), F, d_palette, d_pixels,
+                       width, height, y_origin, weight, seed, d_index, d_argb);
 }
 
 } // namespace nq

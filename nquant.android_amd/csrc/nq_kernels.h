@@ -87,6 +87,8 @@ void launch_fast_closest_tuple(const DevParams& P, const ListsView& lv, const in
                                int* d_out4, hipStream_t s);
 void launch_fast_lookup_only(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_pixels, int64_t N,
                              unsigned short* d_index, int* d_argb, hipStream_t s);
+void launch_fast_bluenoise(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_pixels, int width, int height,
+                           int y_origin, float weight, long long seed, unsigned short* d_index, int* d_argb, hipStream_t s);
 // BlueNoise.dither post-pass (NQ/BlueNoise.java:207-222); in-place on d_index, writes d_argb
 void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_pixels, int width, int height,
                       int y_origin /* band start row in the whole image, 0 otherwise */,
