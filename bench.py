@@ -108,17 +108,20 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # one rank per GPU; a rehearsal with more ranks than GPUs (NQ_BENCH_BACKEND=gloo on a one-GPU box) wraps around
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = os.environ.get("NQ_BENCH_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only to rehearse the multi-rank path
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     elif args.config == "cfg5":
         import torch.distributed as dist       # the band pipeline always talks through a process group (world 1 here)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1)
+        dist.init_process_group(backend, rank=0, world_size=1)
 
     import threading
     import nquant.android_amd as nq
@@ -225,7 +228,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stages = {}
@@ -297,7 +300,7 @@ def _barrier(dist):
 
 def _max_over_ranks(dt, dist):
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
