@@ -152,7 +152,7 @@ __device__ __forceinline__ float tanh_to_float(float xf) {
 
 // ---- closestColorIndex, one candidate, the reference's statement sequence (NQ/PnnLABQuantizer.java:421-445, no semi-transparency,
 // ratio >= 0: every term is >= 0 and the gates only leave early a candidate that neither branch takes) -> err as f64
-__device__ __forceinline__ double closest_err_exact(int c2, int cr, int cg, int cb, double wr, double wg, double wb, double ratio) {
+__device__ __attribute__((noinline)) double closest_err_exact(int c2, int cr, int cg, int cb, double wr, double wg, double wb, double ratio) {
     const int dr = c_red(c2) - cr, dg = c_green(c2) - cg, db = c_blue(c2) - cb;
     double err = wr * sqr((double) dr);
     err += wg * sqr((double) dg);
@@ -250,18 +250,30 @@ __device__ __forceinline__ FastClosest fast_closest_tuple(const FastLds& S, cons
     const int cr = c_red(c), cg = c_green(c), cb = c_blue(c);
     const float crf = (float) cr, cgf = (float) cg, cbf = (float) cb;
     FastClosest t; t.c0 = t.c1 = 0; t.e0 = t.e1 = 2147483647;
-    unsigned w0 = la.x, w1 = la.y, w2 = la.z, w3 = la.w;
-    int k_next = (int) (w0 & 0xFF);
-    int c2_next = S.argb[k_next];
+    // the first eight entries straight-line (the longest list of a wavefront is ~7): their palette words are requested together,
+    // no shift register, no loop control; the rare longer lists continue in the rolled loop
+    {
+        int kk[8], cc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kk[j] = (int) (((j < 4 ? la.x : la.y) >> ((j & 3) * 8)) & 0xFF); cc[j] = S.argb[kk[j]]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < n1) fast_closest_step(t, kk[j], cc[j], crf, cgf, cbf, cr, cg, cb, X.qa, X.qb, X.qc, X.wr, X.wg, X.wb, X.ratio);
+    }
+    if (n1 > 8) {
+        unsigned w0 = la.z, w1 = la.w, w2 = 0u, w3 = 0u;
+        int k_next = (int) (w0 & 0xFF);
+        int c2_next = S.argb[k_next];
 #pragma unroll 1
-    for (int i = 0; i < n1; ++i) {
-        const int k = k_next, c2k = c2_next;
-        w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
-        w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
-        if (i == 14 && n1 > 15) { const uint4 m = X.cont[cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
-        k_next = (int) (w0 & 0xFF);
-        c2_next = S.argb[k_next];
-        fast_closest_step(t, k, c2k, crf, cgf, cbf, cr, cg, cb, X.qa, X.qb, X.qc, X.wr, X.wg, X.wb, X.ratio);
+        for (int i = 8; i < n1; ++i) {
+            const int k = k_next, c2k = c2_next;
+            w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+            w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
+            if (i == 14 && n1 > 15) { const uint4 m = X.cont[cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
+            k_next = (int) (w0 & 0xFF);
+            c2_next = S.argb[k_next];
+            fast_closest_step(t, k, c2k, crf, cgf, cbf, cr, cg, cb, X.qa, X.qb, X.qc, X.wr, X.wg, X.wb, X.ratio);
+        }
     }
     if (t.e1 == 2147483647) t.c1 = t.c0;
     return t;
@@ -275,24 +287,41 @@ __device__ __forceinline__ int fast_nearest(const FastLds& S, const FastLookup& 
     lab32_of(c, S.gamma32, L1, A1, B1);
     float d1 = 3.0e38f, d2 = 3.0e38f;
     int k1 = X.kfirst;
-    unsigned w0 = na.x, w1 = na.y, w2 = na.z, w3 = na.w;
-    int k_next = (int) (w0 & 0xFF);
-    float4 l_next = S.lab[k_next];
+    {
+        int kk[8]; float4 ll[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kk[j] = (int) (((j < 4 ? na.x : na.y) >> ((j & 3) * 8)) & 0xFF); ll[j] = S.lab[kk[j]]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < n2) {
+                const float dA = ll[j].y - A1, dB = ll[j].z - B1;
+                const float d = fabsf(ll[j].x - L1) + __builtin_amdgcn_sqrtf(__builtin_fmaf(dA, dA, dB * dB));
+                const bool lt = d < d1;
+                d2 = lt ? d1 : fminf(d2, d);
+                k1 = lt ? kk[j] : k1;
+                d1 = fminf(d1, d);
+            }
+    }
+    if (n2 > 8) {
+        unsigned w0 = na.z, w1 = na.w, w2 = 0u, w3 = 0u;
+        int k_next = (int) (w0 & 0xFF);
+        float4 l_next = S.lab[k_next];
 #pragma unroll 1
-    for (int i = 0; i < n2; ++i) {
-        const int k = k_next;
-        const float4 l2 = l_next;
-        w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
-        w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
-        if (i == 14 && n2 > 15) { const uint4 m = X.cont[65536 + cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
-        k_next = (int) (w0 & 0xFF);
-        l_next = S.lab[k_next];
-        const float dA = l2.y - A1, dB = l2.z - B1;
-        const float d = fabsf(l2.x - L1) + __builtin_amdgcn_sqrtf(__builtin_fmaf(dA, dA, dB * dB));
-        const bool lt = d < d1;
-        d2 = lt ? d1 : fminf(d2, d);
-        k1 = lt ? k : k1;
-        d1 = fminf(d1, d);
+        for (int i = 8; i < n2; ++i) {
+            const int k = k_next;
+            const float4 l2 = l_next;
+            w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+            w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
+            if (i == 14 && n2 > 15) { const uint4 m = X.cont[65536 + cell]; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
+            k_next = (int) (w0 & 0xFF);
+            l_next = S.lab[k_next];
+            const float dA = l2.y - A1, dB = l2.z - B1;
+            const float d = fabsf(l2.x - L1) + __builtin_amdgcn_sqrtf(__builtin_fmaf(dA, dA, dB * dB));
+            const bool lt = d < d1;
+            d2 = lt ? d1 : fminf(d2, d);
+            k1 = lt ? k : k1;
+            d1 = fminf(d1, d);
+        }
     }
     if (!(d2 - d1 > 2.0f * NQ_FAST_NEAR_EPS)) k1 = fast_nearest_exact(S, c, na, X.cont + 65536 + cell, n2, X.kfirst);
     return k1;
