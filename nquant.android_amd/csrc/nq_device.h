@@ -82,16 +82,16 @@ __device__ __forceinline__ Lab RGB2LAB(int c1) {
     lab.B = (float) (200 * (y - z));
     return lab;
 }
-// Cube root for the PER-PIXEL Lab conversions (nearest fallback, saliency map): hardware exp2/log2 seed for x^(-1/3), two
-// division-free Newton steps, one residual correction with an explicit fma.  Measured against exact arithmetic on 80 000
-// points of [0.008856, 1.2]: <= 0.72 ulp (libm's pow(x, 1/3.0) itself is 1.2 ulp from the true cube root because 1/3.0 is
-// not 1/3).  Every consumer narrows the Lab value to float, so the two agree except with probability ~1e-9 per evaluation.
+// Cube root for the PER-PIXEL Lab conversions (histogram, nearest fallback, saliency map): hardware exp2/log2 seed for x^(-1/3)
+// (3e-7 relative), ONE division-free Newton step (-> 2e-13), one residual correction on y = x r^2 with an explicit fma (-> rounding
+// level).  Measured against exact arithmetic on 20 000 points of [0.008856, 1.2]: <= 0.72 ulp, the same as with two Newton steps
+// (libm's pow(x, 1/3.0) itself is 1.2 ulp from the true cube root because 1/3.0 is not 1/3).  Every consumer narrows the Lab value
+// to float, so the two agree except with probability ~1e-9 per evaluation (tests: the whole 2^24 colour cube, zero flips).
 __device__ __forceinline__ double cbrt_fast(double x) {
     const float r0 = __builtin_amdgcn_exp2f(-0.333333343f * __builtin_amdgcn_logf((float) x));
     double r = (double) r0;
     const double third = 1.0 / 3.0;
-    double r3 = r * r * r; r = r + r * (1.0 - x * r3) * third;
-    r3 = r * r * r; r = r + r * (1.0 - x * r3) * third;
+    const double r3 = r * r * r; r = r + r * (1.0 - x * r3) * third;
     double y = x * r * r;
     const double res = fma(y * y, y, -x);
     return y - res * (r * r) * third;
