@@ -307,7 +307,7 @@ int reserve_palette_ws(nq_handle* h, int64_t n) {
     NQ_HIP(h, h->binf.reserve((size_t) 6 * 65536)); NQ_HIP(h, h->bind.reserve((size_t) 4 * 65536));
     NQ_HIP(h, h->bini.reserve((size_t) 3 * 65536)); NQ_HIP(h, h->heap.reserve(2 * (65536 + 2)));
     NQ_HIP(h, h->live3.reserve((size_t) 3 * 65536));
-    NQ_HIP(h, h->scan_f.reserve((size_t) 2 * 6 * 65536 + 256)); NQ_HIP(h, h->scan_i.reserve((size_t) 2 * 65536));
+    NQ_HIP(h, h->scan_f.reserve((size_t) 2 * 10 * 65536 + 256)); NQ_HIP(h, h->scan_i.reserve((size_t) 2 * 65536));
     NQ_HIP(h, h->scan_box.reserve((size_t) 1024 * 8));
     return NQ_OK;
 }

@@ -217,7 +217,11 @@ void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, float* 
         hipLaunchKernelGGL(init_boxes_kernel, dim3((nblk + 255) / 256), dim3(256), 0, s, B, maxbins, d_box);
         hipLaunchKernelGGL(find_nn_init_lab_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins, (const float*) d_box);
     }
-    else hipLaunchKernelGGL(find_nn_init_kernel<0>, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins);
+    else {
+        const int nblk = (maxbins + 63) / 64;
+        hipLaunchKernelGGL(init_boxes_rgb_kernel, dim3((nblk + 255) / 256), dim3(256), 0, s, B, maxbins, d_box);
+        hipLaunchKernelGGL(find_nn_init_rgb_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins, (const float*) d_box);
+    }
 }
 // one workgroup per job; the workgroup size follows the number of jobs in flight (nq_merge.inc)
 template <typename K>

@@ -22,3 +22,4 @@ print("finds %d merges %d | per find us: total %.2f ctrl %.2f bound %.2f (seed %
     n, st["merges"], st["find_ticks_100MHz"] / n / 100, st["ctrl_ticks_100MHz"] / n / 100, st["bound_ticks"] / n / 100,
     st["seed_round_ticks"] / n / 100, st["exact_ticks"] / n / 100, st["replay_ticks"] / n / 100, st["chunks"] / n, st["chunks_l1"] / n,
     st["chunks_l2"] / n, st["chunks_listed"] / n, st["exact_evals"] / n))
+print("overflows %d rebuilds %d ratio %.4f" % (st["overflows"], st["rebuilds"], q.params.ratio))
