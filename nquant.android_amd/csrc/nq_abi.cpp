@@ -469,6 +469,11 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
     np.kind = kind; np.hasSemi = p.hasSemiTransparency; np.texicab = texicab;
     np.ratio = p.ratio; np.PR = p.PR; np.PG = p.PG; np.PB = p.PB; np.PA = p.PA;
     np.pgLessThanCoeff = p.PG < kCoeffs[0][1];
+    np.rgbTheta = 2.0;
+    if (const char* t = std::getenv("NQ_RGB_THETA")) {           // tests: 1.0 makes the checked assumption fail often (fallback path)
+        const double v = std::atof(t);
+        if (v >= 1.0 && v <= 1e6) np.rgbTheta = v;
+    }
     rec(h, 2);
     launch_find_nn_init(np, B, maxbins, h->scan_box.p, h->stream);
     rec(h, 3);

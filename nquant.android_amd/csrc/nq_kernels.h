@@ -110,6 +110,7 @@ struct NNParams {
     int kind, hasSemi, texicab;
     double ratio, PR, PG, PB, PA;
     int pgLessThanCoeff;
+    double rgbTheta;            // RGB scans: assumed cap of the running error = rgbTheta x error after the seed blocks (>= 1; checked, see nq_merge.inc)
 };
 struct SortWorkspace {
     unsigned short *keys_a, *keys_b;

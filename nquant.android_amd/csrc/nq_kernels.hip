@@ -196,10 +196,12 @@ void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams
     (void) hipMemsetAsync(ws.seg_end, 0, 65536 * sizeof(unsigned), s);
     hipLaunchKernelGGL(seg_bounds_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, ws.keys_b, (long long) n,
                        ws.seg_start, ws.seg_end);
+    const int keyfmt = hp.hasSemi ? 2 : hp.hasTransp ? 1 : 0;          // getColorIndex: 4-4-4-4 / 1-5-5-5 / 5-6-5
     if (kind == 1)
-        hipLaunchKernelGGL(hist_segments_kernel<1>, dim3(65536 / 4), dim3(256), 0, s, ws.vals_b, ws.seg_start, ws.seg_end, d_hist);
+        hipLaunchKernelGGL(hist_segments_kernel<1>, dim3(65536 / 4), dim3(256), keyfmt == 2 ? 0 : (size_t) 4 * (keyfmt == 0 ? 256 : 512) * 16, s,
+                           ws.vals_b, ws.seg_start, ws.seg_end, d_hist, keyfmt);
     else
-        hipLaunchKernelGGL(hist_segments_kernel<0>, dim3(65536 / 4), dim3(256), 0, s, ws.vals_b, ws.seg_start, ws.seg_end, d_hist);
+        hipLaunchKernelGGL(hist_segments_kernel<0>, dim3(65536 / 4), dim3(256), 0, s, ws.vals_b, ws.seg_start, ws.seg_end, d_hist, keyfmt);
 }
 void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, int* d_blockcnt, hipStream_t s) {
     hipLaunchKernelGGL(compact_count_kernel, dim3(64), dim3(1024), 0, s, d_hists, n_bands, d_blockcnt);
@@ -214,7 +216,7 @@ void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, float* 
     if (maxbins <= 0) return;
     if (np.kind == 1) {
         const int nblk = (maxbins + 63) / 64;
-        hipLaunchKernelGGL(init_boxes_kernel, dim3((nblk + 255) / 256), dim3(256), 0, s, B, maxbins, d_box);
+        hipLaunchKernelGGL(init_boxes_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, B, maxbins, d_box);
         hipLaunchKernelGGL(find_nn_init_lab_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins, (const float*) d_box);
     }
     else {

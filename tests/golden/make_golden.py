@@ -31,6 +31,10 @@ CASES = {
 # mtm are too small in every workgroup variant and all 1005 position blocks exist
 PALETTE_CASES = {
     "lab256_palette_uniform_512x512": dict(kind=1, K=256, img=lambda: synth.uniform_rgb(512, 512, 7)),
+    # the RGB kind at the same size (block pruning of the RGB scan, its unpruned fallback, the pruned initial pass), and with
+    # semi-transparent pixels (alpha term of the gate, which the boxes ignore)
+    "rgb256_palette_uniform_512x512": dict(kind=0, K=256, img=lambda: synth.uniform_rgb(512, 512, 7)),
+    "rgb64_palette_alpha_gradient_384x384": dict(kind=0, K=64, img=lambda: synth.with_alpha(synth.gradient_noise(384, 384, 9), 9)),
 }
 
 

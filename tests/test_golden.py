@@ -62,3 +62,22 @@ def test_gpu_reproduces_golden_palette_every_merge_variant(nq, name, threads, mo
     p = q.params
     assert [p.maxbins, p.isNano, p.texicab, p.quan_rt] == list(want["scalars"])
     assert (np.array([p.ratio, p.weight]) == want["doubles"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("theta", ["1.0", "1.25", "64"])
+@pytest.mark.parametrize("name", sorted(n for n in mg.PALETTE_CASES if mg.PALETTE_CASES[n]["kind"] == 0))
+def test_gpu_rgb_palette_does_not_depend_on_the_assumed_error_cap(nq, name, theta, monkeypatch):
+    """The RGB scans prune blocks against an ASSUMED cap of the running error (theta x the error after the seed blocks) and fall back
+    to the unpruned scan when the assumption fails (csrc/nq_merge.inc find_nn_block_rgb_boxes): theta 1.0 fails whenever the error
+    rises (NQ/PnnQuantizer.java:97-113 `break` then err = nerr), 64 prunes next to nothing; the palette must not move."""
+    monkeypatch.setenv("NQ_RGB_THETA", theta)
+    c = mg.PALETTE_CASES[name]
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    q = nq.PnnQuantizer(c["img"](), mode=nq.MODE_PARALLEL_TILED, seed=1)
+    pal = q.pnnquan(c["K"])
+    assert len(pal) == len(want["palette"]) and (pal == want["palette"]).all()
+    st = q.merge_stats()
+    assert st["chunks"] > 0                       # the pruned scan ran
+    if theta == "1.0":
+        assert st["overflows"] > 0                # ... and its fallback

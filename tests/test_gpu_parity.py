@@ -78,7 +78,24 @@ PAL_CASES = [
     # the ratio ladder goes NEGATIVE here (4 colours out of 400 bins, NQ/PnnLABQuantizer.java:259-264): no interval bound holds,
     # the scans must fall back to the exact path (found by tests/fuzz_parity.py)
     (1, 4, lambda: synth.few_colors(128, 148, 508842683, 402)),
+    # 64 histogram bins with ~2300 pixels each, every colour of a bin present: the LAB histogram's per-bin colour table
+    # (hist_segments_kernel, nq_palette.inc) for 5-6-5 keys, for 1-5-5-5 keys (a fully transparent pixel), and with pixels whose
+    # alpha (0xF0) is neither "semi-transparent" nor 255, which bypass the table inside a tabled bin
+    (1, 16, lambda: _crowded_bins(0)),
+    (1, 16, lambda: _crowded_bins(1)),
+    (1, 16, lambda: _crowded_bins(2)),
 ]
+
+
+def _crowded_bins(variant):
+    img = synth.uniform_rgb(384, 384, 41 + variant)
+    img = (img & np.int32(0x00C7C3C7)) | np.int32(-16777216)
+    if variant == 1:
+        img = (img & np.int32(0x00C7C7C7)) | np.int32(-16777216)
+        img[5, 7] = 0x00FFFFFF
+    if variant == 2:
+        img[::3, ::5] = (img[::3, ::5] & 0x00FFFFFF) | np.int32(0xF0000000 - (1 << 32))
+    return img
 
 
 @pytest.mark.parametrize("kind,K,mk", PAL_CASES)

@@ -18,3 +18,7 @@ for it in range(2):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print("kind %d batch %d: %.2f s, %.1f Mpx/s, %.2f ms per image, maxbins %d, stages %s" % (kind, B, dt, B * W * H / dt / 1e6, dt / B * 1e3,
           qs[0].params.maxbins, {k: round(v, 2) for k, v in qs[0].stage_ms().items()}), flush=True)
+st = qs[0].merge_stats(); n = max(st["find_nn_calls"], 1)
+print("image 0 in the batch, per find us: find %.2f ctrl %.2f | bound %.2f (seed %.2f) exact %.2f replay %.2f | chunks %.1f exact evals %.2f overflows %d" % (
+    st["find_ticks_100MHz"] / n / 100, st["ctrl_ticks_100MHz"] / n / 100, st["bound_ticks"] / n / 100, st["seed_round_ticks"] / n / 100,
+    st["exact_ticks"] / n / 100, st["replay_ticks"] / n / 100, st["chunks"] / n, st["exact_evals"] / n, st["overflows"]))
