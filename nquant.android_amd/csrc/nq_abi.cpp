@@ -299,7 +299,6 @@ nq::Bins bins_of(nq_handle* h) {
 }
 
 int reserve_palette_ws(nq_handle* h, int64_t n) {
-    NQ_HIP(h, h->sc->keys_a.reserve((size_t) n)); NQ_HIP(h, h->sc->keys_b.reserve((size_t) n));
     NQ_HIP(h, h->sc->vals_a.reserve((size_t) n)); NQ_HIP(h, h->sc->vals_b.reserve((size_t) n));
     NQ_HIP(h, h->sc->sort_tmp.reserve(sort_temp_bytes(n) + 256));
     NQ_HIP(h, h->sc->seg.reserve(2 * 65536));

@@ -113,8 +113,8 @@ struct NNParams {
     double rgbTheta;            // RGB scans: assumed cap of the running error = rgbTheta x error after the seed blocks (>= 1; checked, see nq_merge.inc)
 };
 struct SortWorkspace {
-    unsigned short *keys_a, *keys_b;
-    int *vals_a, *vals_b;
+    unsigned short *keys_a, *keys_b; // (unused since the histogram sorts packed {bin, rest-of-pixel} words; may be null)
+    int *vals_a, *vals_b;            // [n] each: the packed words before / after the sort
     void* tmp; size_t tmp_bytes;
     unsigned *seg_start, *seg_end;   // [65536]
 };

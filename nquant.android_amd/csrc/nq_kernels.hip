@@ -137,10 +137,13 @@ void launch_bluenoise(const DevParams& P, const int* d_palette, const ListsView&
 }
 
 // ---- palette build launchers ----
+// The histogram sort orders packed words by their upper half only (bits [16, 32)).  rocPRIM 4.2's merge-sort path (default below 2^20
+// keys) does not honour a partial bit range -- measured on gfx950: output not even ordered by those bits -- so the path is switched
+// off (MergeSortLimit 0): single-block sort up to 1024 keys, Onesweep above, both verified stable on the range.
+using HistSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
 size_t sort_temp_bytes(int64_t n) {
     size_t bytes = 0;
-    (void) rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned short*) nullptr, (unsigned short*) nullptr,
-                                     (const int*) nullptr, (int*) nullptr, (size_t) n, 0, 16, (hipStream_t) 0);
+    (void) rocprim::radix_sort_keys<HistSortConfig>(nullptr, bytes, (const unsigned*) nullptr, (unsigned*) nullptr, (size_t) n, 16, 32, (hipStream_t) 0);
     return bytes;
 }
 size_t sort32_temp_bytes(int64_t n, bool pairs) {
@@ -187,21 +190,21 @@ void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long l
 }
 void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams& hp, const SortWorkspace& ws,
                       double* d_hist, hipStream_t s) {
-    hipLaunchKernelGGL(bin_keys_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, hp,
-                       ws.keys_a, ws.vals_a);
+    unsigned* const pk_a = reinterpret_cast<unsigned*>(ws.vals_a);
+    unsigned* const pk_b = reinterpret_cast<unsigned*>(ws.vals_b);
+    hipLaunchKernelGGL(bin_keys_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, hp, pk_a);
     size_t tmp = ws.tmp_bytes;
-    (void) rocprim::radix_sort_pairs(ws.tmp, tmp, (const unsigned short*) ws.keys_a, ws.keys_b, (const int*) ws.vals_a, ws.vals_b,
-                                     (size_t) n, 0, 16, s);
+    (void) rocprim::radix_sort_keys<HistSortConfig>(ws.tmp, tmp, (const unsigned*) pk_a, pk_b, (size_t) n, 16, 32, s);
     (void) hipMemsetAsync(ws.seg_start, 0, 65536 * sizeof(unsigned), s);
     (void) hipMemsetAsync(ws.seg_end, 0, 65536 * sizeof(unsigned), s);
-    hipLaunchKernelGGL(seg_bounds_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, ws.keys_b, (long long) n,
+    hipLaunchKernelGGL(seg_bounds_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, (const unsigned*) pk_b, (long long) n,
                        ws.seg_start, ws.seg_end);
     const int keyfmt = hp.hasSemi ? 2 : hp.hasTransp ? 1 : 0;          // getColorIndex: 4-4-4-4 / 1-5-5-5 / 5-6-5
     if (kind == 1)
         hipLaunchKernelGGL(hist_segments_kernel<1>, dim3(65536 / 4), dim3(256), keyfmt == 2 ? 0 : (size_t) 4 * (keyfmt == 0 ? 256 : 512) * 16, s,
-                           ws.vals_b, ws.seg_start, ws.seg_end, d_hist, keyfmt);
+                           (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt);
     else
-        hipLaunchKernelGGL(hist_segments_kernel<0>, dim3(65536 / 4), dim3(256), 0, s, ws.vals_b, ws.seg_start, ws.seg_end, d_hist, keyfmt);
+        hipLaunchKernelGGL(hist_segments_kernel<0>, dim3(65536 / 4), dim3(256), 0, s, (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt);
 }
 void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, int* d_blockcnt, hipStream_t s) {
     hipLaunchKernelGGL(compact_count_kernel, dim3(64), dim3(1024), 0, s, d_hists, n_bands, d_blockcnt);
