@@ -391,6 +391,115 @@ __device__ __forceinline__ bool ciede_terms_fast(const Lab& lab1, const Lab& lab
     (void) ch_unused; (void) s1; (void) s2_; (void) s3; (void) s4; (void) c5;
     return ok;
 }
+// ---- the same pass spread over the four lanes of a quad (lanes 4k .. 4k+3 hold the SAME pair; r = lane & 3) ----
+// The evaluation is one dependent chain of ~1250 instructions whatever the number of active lanes, and the merge loop waits for it in
+// every find_nn.  Here the independent transcendental evaluations of a pair run side by side in the quad -- the three square roots of
+// stage 1, the two C', the two atan2, the four cosines of T, the two sines -- each lane evaluating the SAME function on its own
+// argument, results broadcast with DPP quad_perm; everything else is computed redundantly by the four lanes.  Every value is produced
+// by the same operations on the same operands as in ciede_terms_fast, so the outputs are identical (nq_selftest_ciede compares them).
+template <int K> __device__ __forceinline__ int quad_bcast_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
+}
+template <int K> __device__ __forceinline__ float quad_bcast(float x) { return __int_as_float(quad_bcast_i<K>(__float_as_int(x))); }
+template <int K> __device__ __forceinline__ double quad_bcast(double x) {
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned) quad_bcast_i<K>((int) (unsigned) b), hi = (unsigned) quad_bcast_i<K>((int) (unsigned) (b >> 32));
+    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+}
+__device__ __forceinline__ bool ciede_terms_fast_quad(const Lab& lab1, const Lab& lab2, int r, float& deltaL, float& deltaC, float& deltaH, float& rt_out) {
+    bool ok = true;
+    const bool second = (r & 1) != 0;
+    const float Aq = second ? lab2.A : lab1.A, Bq = second ? lab2.B : lab1.B;         // lanes 0, 2: colour 1; lanes 1, 3: colour 2
+    // stage 1, three square roots at once: C1 (lane 0), C2 (lane 1), sqrt(20 + p) of S_L (lane 2)        :91-98, :100-104
+    const float deltaLPrime = lab2.L - lab1.L;
+    const float barLPrime = (lab1.L + lab2.L) / 2.0f;
+    const double pL = sqr((double) (barLPrime - 50.0f));
+    const double arg1 = r == 2 ? 20 + pL : (double) ((Aq * Aq) + (Bq * Bq));
+    const double root1 = sqrt(arg1);
+    const float C1 = quad_bcast<0>((float) root1), C2 = quad_bcast<1>((float) root1);
+    const double rootL = quad_bcast<2>(root1);
+    {
+        const float S_L = (float) (1 + (((double) 0.015f * pL) / rootL));
+        deltaL = deltaLPrime / (1.0f * S_L);
+    }
+    const float pow25To7f = 6103515625.0f;
+    const float barC = (C1 + C2) / 2.0f;
+    const double barC7 = nq_pow7((double) barC);
+    const double ratioC = barC7 / (barC7 + (double) pow25To7f);
+    const double Gd = (double) 0.5f * (1 - sqrt(ratioC));
+    ok = ok && nq_narrow_safe(Gd, 6e-16 + 1e-15 * (1.0 - ratioC));
+    const float G = (float) Gd;
+    // stage 2: a' and C' of both colours                                                                   :106-112
+    const double aq = (1.0 + G) * Aq;
+    const double CPq = sqrt((aq * aq) + (double) (Bq * Bq));
+    const double CPrime1 = quad_bcast<0>(CPq), CPrime2 = quad_bcast<1>(CPq);
+    {
+        const float deltaCPrime = (float) CPrime2 - (float) CPrime1;
+        const float barCPrimeF = ((float) CPrime1 + (float) CPrime2) / 2.0f;
+        const float S_C = 1 + (0.045f * barCPrimeF);
+        deltaC = deltaCPrime / S_C;
+    }
+    // stage 3: both hue angles                                                                              :120-140
+    const float deg360InRad = deg2Rad(360.0), deg180InRad = deg2Rad(180.0);
+    const double CPrimeProduct = CPrime1 * CPrime2;
+    double hq = 0.0;
+    if (!((double) Bq == 0.0 && aq == 0.0)) { hq = nq_atan2((double) Bq, aq); if (hq < 0) hq += deg360InRad; }
+    const double hPrime1 = quad_bcast<0>(hq), hPrime2 = quad_bcast<1>(hq);
+    const double AERR = 4e-15;
+    double deltahPrime = 0;
+    if (CPrimeProduct != 0.0) {
+        deltahPrime = hPrime2 - hPrime1;
+        ok = ok && fabs(fabs(deltahPrime) - (double) deg180InRad) > 16 * AERR;
+        if (deltahPrime < -deg180InRad) deltahPrime += deg360InRad;
+        else if (deltahPrime > deg180InRad) deltahPrime -= deg360InRad;
+    }
+    const double hPrimeSum = hPrime1 + hPrime2;
+    double barhPrime;
+    if (CPrimeProduct == 0.0) barhPrime = hPrimeSum;
+    else {
+        if (fabs(hPrime1 - hPrime2) <= deg180InRad) barhPrime = hPrimeSum / 2.0;
+        else {
+            ok = ok && fabs(hPrimeSum - (double) deg360InRad) > 16 * AERR;
+            if (hPrimeSum < deg360InRad) barhPrime = (hPrimeSum + deg360InRad) / 2.0;
+            else barhPrime = (hPrimeSum - deg360InRad) / 2.0;
+        }
+    }
+    const double barCPrime = (CPrime1 + CPrime2) / 2.0;
+    const double bh = barhPrime;
+    // stage 4: the four cosines of T, one per lane                                                          :159-163
+    const double arg4 = r == 0 ? bh - deg2Rad(30.0) : r == 1 ? 2.0 * bh : r == 2 ? (3.0 * bh) + deg2Rad(6.0) : (4.0 * bh) - deg2Rad(63.0);
+    double s4q, c4q;
+    nq_sincos(arg4, s4q, c4q);
+    const double c1 = quad_bcast<0>(c4q), c2 = quad_bcast<1>(c4q), c3 = quad_bcast<2>(c4q), c4 = quad_bcast<3>(c4q);
+    const double T = 1.0 - (0.17 * c1) + (0.24 * c2) + (0.32 * c3) - (0.20 * c4);
+    const double S_H = 1 + ((double) 0.015f * barCPrime * T);
+    // stage 5: exp of R_T (all lanes), then the two sines: sin(dh'/2) (lanes 0, 2), sin(2 dTheta) (lanes 1, 3)   :142, :187-194
+    const double zz = (barhPrime - deg2Rad(275.0)) / deg2Rad(25.0);
+    const double deltaTheta = deg2Rad(30.0) * nq_exp_neg(-(zz * zz));
+    const double arg5 = second ? 2.0 * deltaTheta : deltahPrime / 2.0;
+    double s5q, c5q;
+    nq_sincos(arg5, s5q, c5q);
+    const double sh = quad_bcast<0>(s5q), s5 = quad_bcast<1>(s5q);
+    // stage 6, two square roots at once: sqrt(C1' C2') (lanes 0, 2), sqrt of the R_C ratio (lanes 1, 3)
+    const double bc7 = nq_pow7(barCPrime);
+    const double arg6 = second ? bc7 / (bc7 + 6103515625.0) : CPrimeProduct;
+    const double root6 = sqrt(arg6);
+    const double rootP = quad_bcast<0>(root6), rootR = quad_bcast<1>(root6);
+    const double deltaHPrime = 2.0 * rootP * sh;
+    const double Hd = deltaHPrime / S_H;
+    {
+        const double rel = 1e-13 + (deltahPrime != 0.0 ? 4 * AERR / fabs(deltahPrime) : 0.0);
+        ok = ok && rel < 1e-9 && nq_narrow_safe(Hd, fabs(Hd) * rel);
+    }
+    deltaH = (float) Hd;
+    const double R_C = 2.0 * rootR;
+    const double rtv = ((-s5) * R_C) * deltaC * deltaH;
+    ok = ok && nq_narrow_safe(rtv, fabs(rtv) * 2e-12);
+    rt_out = (float) rtv;
+    (void) s4q; (void) c5q;
+    return ok;
+}
+
 // the same four floats by the literal functions (device library)
 __device__ __forceinline__ void ciede_terms_literal(const Lab& lab1, const Lab& lab2, float& deltaL, float& deltaC, float& deltaH, float& rt_out) {
     deltaL = L_prime_div_k_L_S_L(lab1, lab2);

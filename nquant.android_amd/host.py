@@ -296,7 +296,8 @@ class PnnQuantizer:
         a = np.ascontiguousarray(lab_pairs, np.float32).reshape(-1, 6)
         out = np.zeros((a.shape[0], 9), np.uint32)
         self._check(self._L.nq_selftest_ciede(self._h, a.ctypes.data, a.shape[0], out.ctypes.data))
-        return out[:, 0:4], out[:, 4:8], out[:, 8]
+        self.ciede_quad_identical = (out[:, 8] >> 1) & 1     # the quad-parallel pass (merge loop) gave the same floats and flag
+        return out[:, 0:4], out[:, 4:8], out[:, 8] & 1
 
     def nearestColorIndex(self, palette, colors):
         """short nearestColorIndex(palette, c, pos) on a cache miss, vectorised over `colors`."""

@@ -214,6 +214,9 @@ def test_branch_free_ciede2000_equals_the_literal_functions(nq):
     for k, s in enumerate(sets):
         fast, lit, ok = q.selftest_ciede(s.astype(np.float32))
         dec = ok == 1
+        # the quad-parallel form of the pass (what the merge loop runs: csrc/nq_device.h ciede_terms_fast_quad) gives the same four
+        # floats and the same decided flag as the one-lane form, pair by pair
+        assert q.ciede_quad_identical.all(), "set %d: quad pass differs on %d pairs" % (k, int((q.ciede_quad_identical == 0).sum()))
         bad = (fast[dec] != lit[dec]).any(axis=1)
         assert not bad.any(), "set %d: %d of %d decided pairs differ, first %s" % (k, int(bad.sum()), int(dec.sum()), s[dec][bad][:1])
         decided_total += int(dec.sum())
