@@ -1253,6 +1253,10 @@ static int ditherPixel(GilbertCurve* g, int x, int y, int32_t c2, float beta) {
         float kappa = beta * fmaxf(.05f, .75f - K / 128.0f) * sal[bidx];
         c2 = blue_diffuse(pixel, palette[g->qPixels[bidx]], kappa, strength, x, y);
     }
+    {   /* diagnostics only: does the colour handed to the lookup lie in the 5-6-5 cell of the undithered colour? */
+        const int32_t c0 = c_argb(a_pix, r_pix, g_pix, b_pix);
+        if (((c0 ^ c2) & 0x00F8FCF8) == 0) g_dbg[11]++;
+    }
     return ditherable_nearest(g->dth, palette, K, c2, bidx);
 }
 

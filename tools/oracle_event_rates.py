@@ -26,6 +26,7 @@ t = time.time(); q.dither(pal, True, tile=(tile, tile)); print("dither %.1fs" % 
 c = (C.c_int64 * 16)(); L.nqo_debug_counters(c, 0)
 n = c[0]
 names = {1: "closest calls", 2: "closest -> nearest fallback", 3: "limiter fires", 4: "ditherPixel 2nd stage", 5: "sal>.95 stage", 6: "direct (sal>.99)",
-         7: "closest[2]==0", 8: "closest[2]>=K", 9: "limiter with tanh", 10: "maxErr raised"}
+         7: "closest[2]==0", 8: "closest[2]>=K", 9: "limiter with tanh", 10: "maxErr raised",
+         11: "lookup colour in the 5-6-5 cell of the undithered colour (ditherPixel calls)"}
 for k, v in names.items():
     print("%-32s %10d  %.4f" % (v, c[k], c[k] / max(n, 1)))
