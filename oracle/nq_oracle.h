@@ -79,7 +79,7 @@ int  nqo_dither_tiled(nqo_quantizer* q, const int32_t* palette, int K, int dithe
  * rows of nqo_dither_tiled; pixels outside come back as index 0 / palette[0].  For full-size images checked on a sample of rows. */
 int  nqo_dither_tile_rows(nqo_quantizer* q, const int32_t* palette, int K, int dither, int tile_w, int tile_h,
                           int row_first, int row_count, int32_t* out_argb, int32_t* out_index);
-/* diagnostics: event counters of the per-pixel pass (tools/oracle_event_rates.py) */
+/* diagnostics: event counters of the per-pixel pass (tests/oracle_event_rates.py) */
 void nqo_debug_counters(int64_t* out16, int reset);
 
 /* static GilbertCurve.dither / BlueNoise.dither with caller-supplied saliencies (nullable) and weight; tile <= 0 = sequential */

@@ -1,6 +1,6 @@
 """Event rates of the per-pixel pass (CPU oracle, tiled decomposition): how often closestColorIndex falls back to
 nearestColorIndex, how often the error limiter fires, ... -- the numbers the dither kernel's fast paths are sized for.
-Usage: python tools/oracle_event_rates.py [size] [tile]"""
+Usage: python tests/oracle_event_rates.py [size] [tile]"""
 import ctypes as C
 import os
 import sys

@@ -270,7 +270,7 @@ def test_tiled_output_within_the_stated_deltaE_tolerance_of_the_sequential_refer
     stated per pixel against the SOURCE (CIE76: p50 / p99 of the tiled output no worse than the sequential output's by more than
     5 % + 0.1, p99.9 by more than 10 % + 0.5, the single worst pixel by more than 50 %), on the 8x8 local means between the two outputs (p99 <= 20 % of the sequential
     output's per-pixel p99, i.e. the patterns integrate to the same colours) and on the tile seams (mean Lab step across tile
-    boundaries <= 1.05 x the step inside the tiles).  Measured (tools/tiled_vs_sequential.py): e.g. bench image p50/p99/max
+    boundaries <= 1.05 x the step inside the tiles).  Measured (tests/tiled_vs_sequential.py): e.g. bench image p50/p99/max
     1.15/3.72/6.79 tiled vs 1.15/3.71/6.93 sequential, local means p99 0.31, seam ratio 1.008."""
     img = mk()
     s = 9 if seed is None else seed

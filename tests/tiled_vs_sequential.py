@@ -2,7 +2,7 @@
 per-pixel CIE76 deltaE against the SOURCE image (p50 / p99 / max) for the sequential and the tiled output, deltaE between
 the two outputs after an 8x8 box filter (do the dither patterns integrate to the same colours?), and a tile-seam metric (mean
 absolute Lab step across tile boundaries relative to the same step one pixel inside the tiles).
-Usage: python tools/tiled_vs_sequential.py [size] [tile]"""
+Usage: python tests/tiled_vs_sequential.py [size] [tile]"""
 import os
 import sys
 
