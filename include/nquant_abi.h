@@ -54,7 +54,7 @@ enum nq_status {
 };
 
 /* Scalars convert() derives and the later stages consume.  Same layout as the
- * oracle's nqo_params. */
+ * CPU oracle's parameter struct (tests compare the two field by field). */
 typedef struct nq_params {
     int32_t kind;
     int32_t nMaxColors;

@@ -33,6 +33,26 @@ def test_library_does_not_link_the_oracle(nq):
     assert "nqo_" not in syms
 
 
+def test_only_tests_smoke_and_the_cpu_baseline_touch_the_oracle():
+    """oracle/ is test infrastructure: no file of the package, of tools/ or of include/ may import, load or name it; bench.py may
+    only inside cpu_baseline(), __graft_entry__ only in build() (compiling the checker) and smoke()."""
+    pat = re.compile(r"oracle_lib|libnq_oracle|nqo_[a-z]|import\s+oracle|from\s+oracle")
+    offenders = []
+    for top in ("nquant.android_amd", "nquant", "tools", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if not f.endswith((".py", ".h", ".hip", ".inc", ".cpp", ".c", ".sh", ".java")):
+                    continue
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                if pat.search(text):
+                    offenders.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
+    assert offenders == [], offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    body = bench[bench.index("def cpu_baseline("):]
+    body = body[:body.index("\ndef ", 10)]
+    assert "oracle_lib" in body and "oracle_lib" not in bench.replace(body, "")
+
+
 @pytest.mark.skipif(HAS_GPU, reason="checks the no-device error path")
 def test_no_cpu_fallback(nq):
     with pytest.raises(nq.NqError) as e:
