@@ -135,6 +135,7 @@ struct Scratch {
     DevBuf<unsigned char> sort_tmp;
     DevBuf<unsigned> seg;             // start[65536], end[65536]
     DevBuf<double> hist;              // [65536][5]
+    DevBuf<int> init_cand;            // initial LAB pass: candidate lists {bin, bound}[65536][128], then the counts [65536]
     DevBuf<unsigned char> cell_lists; // closest lists, nearest lists (65536 x 32 each), then their counts (65536 each)
     DevBuf<float> saliency;           // saliency map of the image being dithered
     DevBuf<unsigned> dk_a, dk_b, di_a, di_b;   // distinct-colour sort scratch
@@ -303,6 +304,7 @@ int reserve_palette_ws(nq_handle* h, int64_t n) {
     NQ_HIP(h, h->sc->sort_tmp.reserve(sort_temp_bytes(n) + 256));
     NQ_HIP(h, h->sc->seg.reserve(2 * 65536));
     NQ_HIP(h, h->sc->hist.reserve((size_t) 65536 * 5));
+    if (h->kind == 1) NQ_HIP(h, h->sc->init_cand.reserve((size_t) 65536 * 128 * 2 + 65536));
     NQ_HIP(h, h->binf.reserve((size_t) 6 * 65536)); NQ_HIP(h, h->bind.reserve((size_t) 4 * 65536));
     NQ_HIP(h, h->bini.reserve((size_t) 3 * 65536)); NQ_HIP(h, h->heap.reserve(2 * (65536 + 2)));
     NQ_HIP(h, h->live3.reserve((size_t) 3 * 65536));
@@ -474,7 +476,7 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
         if (v >= 1.0 && v <= 1e6) np.rgbTheta = v;
     }
     rec(h, 2);
-    launch_find_nn_init(np, B, maxbins, h->scan_box.p, h->stream);
+    launch_find_nn_init(np, B, maxbins, h->scan_box.p, h->sc->init_cand.p, h->stream);
     rec(h, 3);
     if (kind == NQ_KIND_LAB) {
         // NQ/PnnLABQuantizer.java:259-264: ratio retuned AFTER the initial pass

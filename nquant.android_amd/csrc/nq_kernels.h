@@ -133,7 +133,8 @@ void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams
 void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, int* d_blockcnt, hipStream_t s);
 void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s);
 // d_box: float[1024 * 8] scratch (LAB: bounding boxes of the blocks of 64 consecutive bins)
-void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, float* d_box, hipStream_t s);
+// d_init_cand: int[65536 * 128 * 2 + 65536] scratch of the LAB kind (candidate lists between the bound and the exact kernel); may be null for RGB
+void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, float* d_box, int* d_init_cand, hipStream_t s);
 // One merge loop (P9).  heap: int[2*(65536+2)] (ids, then float keys); live3: int[3*65536] (two live lists + position index);
 // scan_f: float[2*10*65536 + 256] (LAB uses 2 x 6 x 65536, RGB 2 x 10 x 65536; a scan may read 63 records past the live list), scan_i: int[2*65536] (LAB scan arrays, two generations); stats: long long[16] (see merge_kernel)
 struct MergeJob {

@@ -215,12 +215,17 @@ void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s) {
     if (fn == 0 || maxbins <= 0) return;
     hipLaunchKernelGGL(quanfn_kernel, dim3((maxbins + 255) / 256), dim3(256), 0, s, d_cnt, maxbins, fn);
 }
-void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, float* d_box, hipStream_t s) {
+void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, float* d_box, int* d_init_cand, hipStream_t s) {
     if (maxbins <= 0) return;
     if (np.kind == 1) {
         const int nblk = (maxbins + 63) / 64;
-        hipLaunchKernelGGL(init_boxes_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, B, maxbins, d_box);
-        hipLaunchKernelGGL(find_nn_init_lab_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins, (const float*) d_box);
+        int2* cand = reinterpret_cast<int2*>(d_init_cand);
+        int* ncand = d_init_cand + (size_t) 65536 * 128 * 2;
+        if (np.ratio >= 0.0 && np.ratio <= 1.0) {
+            hipLaunchKernelGGL(init_boxes_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, B, maxbins, d_box);
+            hipLaunchKernelGGL(find_nn_init_lab_bounds_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins, (const float*) d_box, cand, ncand);
+        }
+        hipLaunchKernelGGL(find_nn_init_lab_exact_kernel, dim3((maxbins + 3) / 4), dim3(256), 0, s, np, B, maxbins, (const int2*) cand, (const int*) ncand);
     }
     else {
         const int nblk = (maxbins + 63) / 64;
