@@ -116,7 +116,8 @@ struct SortWorkspace {
     unsigned short *keys_a, *keys_b; // (unused since the histogram sorts packed {bin, rest-of-pixel} words; may be null)
     int *vals_a, *vals_b;            // [n] each: the packed words before / after the sort
     void* tmp; size_t tmp_bytes;
-    unsigned *seg_start, *seg_end;   // [65536]
+    unsigned *seg_start, *seg_end;   // [65536] each, contiguous (seg_end = seg_start + 65536), followed by the occupied-bin counter (seg_end[65536])
+                                     // and, 64 words further, the list of the occupied bins [65536]
 };
 size_t sort_temp_bytes(int64_t n);
 size_t sort32_temp_bytes(int64_t n, bool pairs);

@@ -195,16 +195,20 @@ void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams
     hipLaunchKernelGGL(bin_keys_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, hp, pk_a);
     size_t tmp = ws.tmp_bytes;
     (void) rocprim::radix_sort_keys<HistSortConfig>(ws.tmp, tmp, (const unsigned*) pk_a, pk_b, (size_t) n, 16, 32, s);
-    (void) hipMemsetAsync(ws.seg_start, 0, 65536 * sizeof(unsigned), s);
-    (void) hipMemsetAsync(ws.seg_end, 0, 65536 * sizeof(unsigned), s);
+    unsigned* const occ_count = ws.seg_end + 65536;             // (seg_start, seg_end, the counter: one contiguous clear)
+    unsigned* const occ_list = occ_count + 64;
+    (void) hipMemsetAsync(ws.seg_start, 0, (2 * 65536 + 1) * sizeof(unsigned), s);
+    (void) hipMemsetAsync(d_hist, 0, (size_t) 65536 * 5 * sizeof(double), s);        // empty bins are not visited any more
     hipLaunchKernelGGL(seg_bounds_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, (const unsigned*) pk_b, (long long) n,
                        ws.seg_start, ws.seg_end);
+    hipLaunchKernelGGL(occupied_bins_kernel, dim3(64), dim3(1024), 0, s, (const unsigned*) ws.seg_start, (const unsigned*) ws.seg_end, occ_count, occ_list);
     const int keyfmt = hp.hasSemi ? 2 : hp.hasTransp ? 1 : 0;          // getColorIndex: 4-4-4-4 / 1-5-5-5 / 5-6-5
     if (kind == 1)
         hipLaunchKernelGGL(hist_segments_kernel<1>, dim3(65536 / 4), dim3(256), keyfmt == 2 ? 0 : (size_t) 4 * (keyfmt == 0 ? 256 : 512) * 16, s,
-                           (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt);
+                           (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt, (const unsigned*) occ_count, (const unsigned*) occ_list);
     else
-        hipLaunchKernelGGL(hist_segments_kernel<0>, dim3(65536 / 4), dim3(256), 0, s, (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt);
+        hipLaunchKernelGGL(hist_segments_kernel<0>, dim3(65536 / 4), dim3(256), 0, s, (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt,
+                           (const unsigned*) occ_count, (const unsigned*) occ_list);
 }
 void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, int* d_blockcnt, hipStream_t s) {
     hipLaunchKernelGGL(compact_count_kernel, dim3(64), dim3(1024), 0, s, d_hists, n_bands, d_blockcnt);
