@@ -14,8 +14,12 @@ Prints ONE JSON line on rank 0 (contract in the round prompt) with extra objects
                     8 B/pixel (4 B ARGB read + 4 B ARGB write) / its average duration measured with HIP
                     events on the launch stream inside the timed region, against the 8 TB/s HBM peak;
   roofline_whole -- the same 8 B/pixel against the time of the WHOLE convert per image (all stages);
-  cpu_baseline   -- the CPU oracle (C restatement of the reference's sequential Java path, 1 core) on a bounded sample
-                    of the same workload (the sample size is in its "sample" field), rank 0, N=1 only.
+  roofline_lookup -- fast_lookup_only_kernel (MODE_LOOKUP_ONLY: nearestColorIndex per pixel, the "dither off, bit-exact indices" half
+                    of the north star) on the same image and palette, measured after the timed region: 4 B read + 2 B index +
+                    4 B ARGB written = 10 B/pixel against its HIP-event time;
+  amortised_ms_per_image -- the three phases of a batch call (HIP events on the launch stream) divided by the batch size;
+  cpu_baseline   -- the CPU oracle (C restatement of the reference's sequential Java path, 1 core) on the SAME 4096x4096 image
+                    and seed as slot 0 of the batch (--cpu-sample shrinks it; the size is in its "sample" field), rank 0, N=1 only.
 
 --config cfg3 (default) is the headline above.  The other two BASELINE configurations exercise the multi-GPU shapes:
   --config cfg4  batch of 64 x 1920x1080 frames, frame f on rank f mod N (independent units, no data-path collective; strong scaling);
@@ -57,9 +61,10 @@ def cpu_baseline(workload, sample):
     q.convert(256, True)
     dt = time.perf_counter() - t0
     st = q.stage_seconds()
+    what = "the headline image itself (slot 0 of the batch, seed 3)" if sample == 4096 else "a bounded sample, NOT the 4096x4096 image of the headline"
     return {"value": round(sample * sample / dt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": "%dx%d %s (a bounded sample, NOT the 4096x4096 image of the headline), whole convert(256,true), sequential C "
-                      "restatement of the reference Java path, %.1f s (pnnquan %.1f s, dither %.1f s)" % (sample, sample, workload, dt,
+            "sample": "%dx%d %s, seed 3 (%s), ONE whole convert(256,true), sequential C restatement of the reference Java path, "
+                      "%.1f s (pnnquan %.1f s, dither %.1f s)" % (sample, sample, workload, what, dt,
                                                             st["histogram"] + st["nn_init"] + st["merge"], st["gilbert"]),
             "nproc": os.cpu_count()}
 
@@ -89,7 +94,10 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform"])
     ap.add_argument("--tile", type=int, default=0, help="tile side of the PARALLEL_TILED decomposition (0 = automatic)")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="side of the CPU-baseline sample image (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4096,
+                    help="side of the CPU-baseline image (default: the headline's own 4096, ~80 s on one core; 0 = skip)")
+    ap.add_argument("--no-dither", action="store_true", help="cfg5 only: convert(256, dither=false) -- the BlueNoise leg with the image-wide "
+                                                             "distinct-colour count (presence-table all-reduce)")
     ap.add_argument("--batch", type=int, default=1024,
                     help="images per step (distinct synthetic images, all resident in HBM): the merge loop of one image is a "
                          "sequential chain on one CU, a batch runs its merge loops side by side (nq_convert_batch_device)")
@@ -175,7 +183,7 @@ def main():
         o += share[t]
         st = torch.cuda.Stream()
         g[0]["q"].set_stream(st.cuda_stream)          # a batch runs on its first handle's stream
-        groups.append({"slots": g, "stream": st, "stages": {}, "n": 0, "pals": None, "err": None, "index": t})
+        groups.append({"slots": g, "stream": st, "stages": {}, "phases": {}, "n": 0, "pals": None, "err": None, "index": t})
 
     def run_group(gr, nsteps, record):
         # one host thread per sub-batch: the C ABI blocks only on its own stream (ctypes releases the GIL)
@@ -187,6 +195,8 @@ def main():
                 gr["pals"] = nq.convert_batch_device([s["q"] for s in sl], [s["in"].data_ptr() for s in sl], 256, True,
                                                      [s["out"].data_ptr() for s in sl], [s["idx"].data_ptr() for s in sl])
                 if record:
+                    for k, v in sl[0]["q"].batch_phase_ms().items():      # phases of the batch call (events on the launch stream)
+                        gr["phases"][k] = gr["phases"].get(k, 0.0) + v
                     for s in sl:
                         for k, v in s["q"].stage_ms().items():      # HIP events recorded on the launch stream, per stage
                             gr["stages"][k] = gr["stages"].get(k, 0.0) + v
@@ -237,6 +247,11 @@ def main():
         for k, v in gr["stages"].items():
             stages[k] = stages.get(k, 0.0) + v
     stages = {k: v / max(nrec, 1) for k, v in stages.items()}
+    phases = {}
+    for gr in groups:
+        for k, v in gr["phases"].items():
+            phases[k] = phases.get(k, 0.0) + v
+    phases = {k: v / max(nrec, 1) for k, v in phases.items()}        # per image: a group's phase span / its images, averaged over the steps
     pals = groups[0]["pals"]
     # sanity of the timed work itself: every output pixel is its palette entry, palettes are full and differ between images
     g0 = groups[0]
@@ -248,6 +263,18 @@ def main():
     if len(g0["slots"]) > 1 and bool((pals[0] == pals[-1]).all()):
         raise SystemExit("bench: distinct images produced identical palettes")
 
+    # LOOKUP_ONLY (nearestColorIndex per pixel, no diffusion) on slot 0 with its palette: the HBM-streaming kernel of the path
+    lookup_ms = None
+    if rank == 0:
+        reps = 20
+        acc = 0.0
+        for r in range(reps + 2):
+            q0.dither_device(slots[0]["in"].data_ptr(), pals[0], False, slots[0]["out"].data_ptr(), slots[0]["idx"].data_ptr(),
+                             mode=nq.MODE_LOOKUP_ONLY)
+            torch.cuda.synchronize()
+            if r >= 2:
+                acc += q0.stage_ms()["dither"]
+        lookup_ms = acc / reps
     if rank == 0:
         p = q0.params
         kernel_ms = stages["dither"]
@@ -269,7 +296,11 @@ def main():
                        "batch": Bn, "concurrency": T, "images_per_s": round(world * images / dt, 2),
                        "ms_per_image": round(dt / images * 1e3, 3),
                        "single_convert_latency_ms": round(latency_ms, 2)},
-            "stages_ms": {k: round(v, 3) for k, v in stages.items()},
+            "amortised_ms_per_image": {"prepare (pre-scan + histogram + initial find_nn pass)": round(phases.get("prepare", 0.0), 4),
+                                       "merge (all merge loops of the batch in one launch + palette fill)": round(phases.get("merge", 0.0), 4),
+                                       "finish (palette read-back + candidate lists + saliency + dither pass)": round(phases.get("finish", 0.0), 4),
+                                       "of which the dither kernel": round(kernel_ms, 4),
+                                       "sum": round(phases.get("total", 0.0), 4)},
             "single_convert_stages_ms": {k: round(v, 3) for k, v in single_stages.items()},
             "merge_stats": single_merge_stats,
             "pass_mpixels_s": round(npx / (kernel_ms * 1e-3) / 1e6, 1) if kernel_ms > 0 else None,
@@ -278,6 +309,13 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": measured_traffic(W, H),
                          "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * npx, "kernel_ms": round(kernel_ms, 3)},
         }
+        LOOKUP_BYTES = 10          # 4 B ARGB read + 2 B index + 4 B ARGB written
+        if lookup_ms and lookup_ms > 0:
+            la = LOOKUP_BYTES * npx / (lookup_ms * 1e-3) / 1e9
+            line["roofline_lookup"] = {"bound": "hbm", "kernel": "fast_lookup_only_kernel (MODE_LOOKUP_ONLY: per-pixel nearestColorIndex, csrc/nq_dither_fast.hip)",
+                                       "achieved": round(la, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(la / HBM_PEAK_GBPS, 5),
+                                       "traffic": None, "algorithmic_bytes_per_launch": LOOKUP_BYTES * npx, "kernel_ms": round(lookup_ms, 4),
+                                       "mpixels_s": round(npx / (lookup_ms * 1e-3) / 1e6, 1)}
         whole_ms = dt / images * 1e3 * world        # time one rank spends per image, all stages
         line["roofline_whole"] = {"bound": "hbm", "what": "8 B/pixel over the whole convert() of one image (all stages, batch amortised)",
                                   "achieved": round(BYTES_PER_PIXEL * npx / (whole_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -377,7 +415,7 @@ def bench_cfg5(args, nq, synth, dist, rank, local_rank, world):
 
     def step():
         with torch.cuda.stream(st):
-            return parallel.convert_banded(q, d_band, W, rows, y0, 256, True, d_out, d_idx, image_height=H, timings=timings)
+            return parallel.convert_banded(q, d_band, W, rows, y0, 256, not args.no_dither, d_out, d_idx, image_height=H, timings=timings)
     for _ in range(args.warmup):
         step()
     timings.clear()
@@ -399,7 +437,8 @@ def bench_cfg5(args, nq, synth, dist, rank, local_rank, world):
         achieved = BYTES_PER_PIXEL * band_px / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         hist_bytes = 65536 * 5 * 8
         print(json.dumps({
-            "metric": "Mpixels/sec, 16384x16384 RGBA tiled across the GPUs -> 256-colour PnnLAB + dither (RCCL histogram exchange)",
+            "metric": "Mpixels/sec, 16384x16384 RGBA tiled across the GPUs -> 256-colour PnnLAB%s (RCCL histogram exchange)"
+                      % (", dither=false + BlueNoise post-pass" if args.no_dither else " + dither"),
             "value": round(args.steps * W * H / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",

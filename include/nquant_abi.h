@@ -74,6 +74,9 @@ typedef struct nq_params {
 
 /* ---- lifetime: replaces `new PnnQuantizer(fname)` / `new PnnLABQuantizer(fname)` (NQ/PnnQuantizer.java:35,
  *      NQ/PnnLABQuantizer.java:24) and garbage collection.  device = HIP device ordinal. ---- */
+/* Threads and devices: a handle is NOT thread-safe (like the reference object); distinct handles are independent and
+ * may be driven from different threads and live on different devices of one process -- all per-device state (constant tables,
+ * kernel attributes) is set up per handle on the handle's device, nothing is cached per process. */
 int nq_create(int kind, int device, nq_handle** out);
 void nq_destroy(nq_handle* h);
 const char* nq_last_error(const nq_handle* h);   /* h may be NULL: last error of nq_create on this thread */
@@ -238,6 +241,12 @@ int nq_get_stage_ms(const nq_handle* h, float* out8);
  * the bound pass, ticks in the exact pass, ticks in the replay, 64-candidate chunks visited, chunks that ran the level-1
  * bound, chunks that ran the tight bound, chunks that listed a candidate, aborted flag, ticks of the seed round inside the bound pass}. */
 int nq_get_merge_stats(const nq_handle* h, int64_t* out16);
+/* Phases of the last nq_convert_batch[_device] call, as seen by its FIRST handle: HIP-event spans on the launch stream, ms:
+ * {every image's pre-scan + histogram + initial find_nn pass, the merge launch (all merge loops side by side + palette fill),
+ *  every image's palette read-back + candidate lists + dither pass, whole call}.  Divided by the batch size these are the
+ * amortised per-image times (the per-handle stage times of nq_get_stage_ms are event spans that include queueing behind the
+ * other images of the batch). */
+int nq_get_batch_phase_ms(const nq_handle* h0, float* out4);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,15 @@ UNITS = {
 }
 
 
+STAMP = os.path.join(CSRC, ".build_flags")
+
+
+def _flags():
+    """Everything outside the sources that changes the objects: the timing-experiment switches must never leak into a later normal build."""
+    return "debug=%s knockout=%s hipcc=%s common=%s" % (bool(os.environ.get("NQ_BUILD_DEBUG")), bool(os.environ.get("NQ_BUILD_KNOCKOUT")),
+                                                     HIPCC, " ".join(COMMON))
+
+
 def _newer(target, sources):
     if not os.path.exists(target):
         return True
@@ -30,6 +39,13 @@ def build(force=False, verbose=False):
     """Compiles the translation units whose sources changed (in parallel) and links libnquant_hip.so."""
     procs, objs = [], []
     me = os.path.abspath(__file__)
+    flags = _flags()
+    try:
+        same_flags = open(STAMP).read() == flags
+    except OSError:
+        same_flags = False            # objects of unknown origin (if any): rebuild
+    if not same_flags:
+        force = True
     for src, (kind, deps) in UNITS.items():
         o = os.path.join(CSRC, src + ".o")
         objs.append(o)
@@ -47,6 +63,9 @@ def build(force=False, verbose=False):
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
+    if procs:
+        with open(STAMP, "w") as f:
+            f.write(flags)
     if procs or force or _newer(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -182,6 +182,8 @@ struct nq_handle {
     hipStream_t copy_stream = nullptr;
     hipStream_t lane_stream = nullptr;  // second lane of the batch entry points
     long long merge_stats[16] = {0};
+    hipEvent_t bev[4] = {nullptr};    // batch entry points: phase boundaries on the launch stream (first handle of the batch)
+    float batch_phase_ms[4] = {0};
     bool ext_distinct_valid = false, ext_distinct_many = false;  // nq_set_distinct: image-wide distinct colours (first-occurrence order) of the split pipeline
     std::vector<int32_t> ext_distinct;
     DevBuf<int> d_ints;               // [0] maxbins, [1] status, [8..71] occupied slots per 1024-slot slice
@@ -195,6 +197,7 @@ struct nq_handle {
     ~nq_handle() {
         for (auto& kv : paths) (void) hipFree(kv.second);
         for (auto& e : ev) if (e) (void) hipEventDestroy(e);
+        for (auto& e : bev) if (e) (void) hipEventDestroy(e);
         if (copy_stream) (void) hipStreamDestroy(copy_stream);
         if (lane_stream) (void) hipStreamDestroy(lane_stream);
     }
@@ -221,6 +224,7 @@ int use_device(nq_handle* h) {
         NQ_HIP(h, h->d_ints.reserve(8 + 64));
         NQ_HIP(h, h->d_bincache.reserve(65536));
         for (auto& e : h->ev) NQ_HIP(h, hipEventCreate(&e));
+        for (auto& e : h->bev) NQ_HIP(h, hipEventCreate(&e));
         h->tables_ready = true;
     }
     return NQ_OK;
@@ -237,6 +241,9 @@ DevParams dev_params(const nq_handle* h, int K) {
     d.PR = p.PR; d.PG = p.PG; d.PB = p.PB; d.PA = p.PA; d.ratio = p.ratio; d.weight = p.weight;
     return d;
 }
+
+// the packed list records of the specialised kernels (nq_dither_fast.hip) live behind the lists and their counts
+void* packed_lists(nq_handle* h) { return h->sc->cell_lists.p + 2 * (size_t) 65536 * 32 + 2 * 65536; }
 
 // candidate lists per colour cell for this palette (nq_lists.inc); empty view = full scans
 int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
@@ -269,11 +276,10 @@ int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
     // (a negative ratio makes the closest error non-monotone in its terms: the list argument does not hold, full scans)
     if (!(h->kind == NQ_KIND_LAB && P.ratio < 0)) { out->closest = base; out->closestCount = base + 2 * LB; }
     if (nearest) { out->nearest = base + LB; out->nearestCount = base + 2 * LB + 65536; }
+    if (h->use_fast_dither && fast_lookup_eligible(P, *out)) launch_pack_lists(*out, packed_lists(h), h->stream);
     return NQ_OK;
 }
 
-// the packed list records of the specialised kernels (nq_dither_fast.hip) live behind the lists and their counts
-void* packed_lists(nq_handle* h) { return h->sc->cell_lists.p + 2 * (size_t) 65536 * 32 + 2 * 65536; }
 
 int get_path(nq_handle* h, int w, int hgt, const uint32_t** out) {
     auto key = std::make_pair(w, hgt);
@@ -533,7 +539,7 @@ int palette_finish(nq_handle* h, const PaletteJob& job, uint32_t* out_palette, i
     NQ_HIP(h, hipMemcpyAsync(h->merge_stats, h->d_scalars.p + 4, sizeof h->merge_stats, hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
     NQ_HIP(h, hipGetLastError());
-    if (h->merge_stats[14]) NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "merge loop stopped by its watchdog (more than maxbins^2/2 find_nn calls, or an empty heap)");
+    if (h->merge_stats[14]) NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "merge loop stopped by its watchdog (more than maxbins^2/2 find_nn calls, 240 s of wall clock, or an empty heap)");
     if (status) NQ_FAIL(h, NQ_ERR_REFERENCE_THROWS, "ColorUtils.setAlphaComponent: alpha outside 0..255 (the reference throws IllegalArgumentException)");
     p.paletteLength = plen;
     *out_K = plen;
@@ -611,17 +617,23 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     NQ_HIP(h, h->d_palette.reserve((size_t) std::max(K, 2)));
     NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (!d_out_index) { NQ_HIP(h, h->d_out_index.reserve((size_t) n)); d_out_index = h->d_out_index.p; }
+    // stage events 5..7 belong to THIS call only once it has recorded all of them (set at the successful exits below); until then
+    // nq_get_stage_ms reports what the last finished convert left
+    h->dither_events_fresh = false;
 
     if (mode == NQ_MODE_LOOKUP_ONLY) {
         DevParams P = dev_params(h, K);
         nq::ListsView lv;
         int rcl = prepare_lists(h, P, &lv);
         if (rcl) return rcl;
+        rec(h, 5);       // stage "dither" = the lookup kernel alone (the candidate lists are built in front of it), "bluenoise" = 0
         if (h->use_fast_dither && fast_lookup_eligible(P, lv))
             launch_fast_lookup_only(P, lv, h->d_palette.p, packed_lists(h), (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
         else
             launch_lookup_only(P, h->d_palette.p, lv, (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
+        rec(h, 6); rec(h, 7);
         NQ_HIP(h, hipGetLastError());
+        h->dither_events_fresh = true;
         return NQ_OK;
     }
     if (mode != NQ_MODE_PARALLEL_TILED && mode != NQ_MODE_REFERENCE_SEQUENTIAL) NQ_FAIL(h, NQ_ERR_INVALID, "unknown mode %d", mode);
@@ -727,8 +739,8 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     if (!sequential && h->use_fast_dither && gilbert_fast_eligible(P, G, T, lv)) {
         // production path (nq_dither_fast.hip); the tiles it cannot finish come back as a list for the generic kernel below
         NQ_HIP(h, h->d_failed.reserve((size_t) T.tiles_x * T.tiles_y + 1));
-        launch_gilbert_fast(P, G, T, lv, (const int*) d_argb, d_sal, h->d_palette.p, (long long) seed, d_out_index,
-                            post ? nullptr : (int*) d_out_argb, h->d_failed.p, packed_lists(h), h->stream);
+        NQ_HIP(h, launch_gilbert_fast(P, G, T, lv, (const int*) d_argb, d_sal, h->d_palette.p, (long long) seed, d_out_index,
+                                      post ? nullptr : (int*) d_out_argb, h->d_failed.p, packed_lists(h), h->stream));
         d_tile_list = h->d_failed.p;
         h->last_dither_fast = 1;
     }
@@ -766,6 +778,7 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
                          h->d_bincache.p, h->d_scalars.p, d_out_index, (int*) d_out_argb, h->stream);
     rec(h, 7);
     NQ_HIP(h, hipGetLastError());
+    h->dither_events_fresh = true;
     return NQ_OK;
 }
 
@@ -780,6 +793,17 @@ void finish_timing(nq_handle* h) {
     if (hipEventElapsedTime(&tot, h->ev[0], h->ev[7]) != hipSuccess) tot = 0;
     h->stage_ms[7] = tot;
     h->dither_events_fresh = false;
+}
+
+void finish_batch_timing(nq_handle* h0) {
+    for (int i = 0; i < 3; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h0->bev[i], h0->bev[i + 1]) != hipSuccess) ms = 0;
+        h0->batch_phase_ms[i] = ms;
+    }
+    float tot = 0;
+    if (hipEventElapsedTime(&tot, h0->bev[0], h0->bev[3]) != hipSuccess) tot = 0;
+    h0->batch_phase_ms[3] = tot;
 }
 
 } // namespace
@@ -896,6 +920,11 @@ int nq_get_merge_stats(const nq_handle* h, int64_t* out8) {
     std::memcpy(out8, h->merge_stats, 16 * sizeof(long long));
     return NQ_OK;
 }
+int nq_get_batch_phase_ms(const nq_handle* h0, float* out4) {
+    if (!h0 || !out4) return NQ_ERR_INVALID;
+    std::memcpy(out4, h0->batch_phase_ms, sizeof h0->batch_phase_ms);
+    return NQ_OK;
+}
 int nq_get_stage_ms(const nq_handle* h, float* out8) {
     if (!h || !out8) return NQ_ERR_INVALID;
     std::memcpy(out8, h->stage_ms, sizeof h->stage_ms);
@@ -932,7 +961,6 @@ int nq_dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height
     if (!h) return NQ_ERR_INVALID;
     int rc = use_device(h);
     if (rc) return rc;
-    h->dither_events_fresh = true;
     return dither_device(h, d_argb, width, height, palette, K, dither, rng_seed, mode, d_out_argb, d_out_index);
 }
 
@@ -1063,6 +1091,7 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
     for (int i = 0; i < n; ++i) { hs[i]->stream = lane_s[i & 1]; hs[i]->sc = lane_sc[i & 1]; }
     std::vector<PaletteJob> jobs(n);
     std::vector<const PaletteJob*> jp(n);
+    (void) hipEventRecord(h0->bev[0], lane_s[0]);
     for (int i = 0; i < n; ++i) {
         int rc = pnnquan_prepare(hs[i], d_argb[i], widths[i], heights[i], nMaxColors, out_palettes + (size_t) i * palette_stride,
                                  out_K + i, &jobs[i]);
@@ -1070,8 +1099,10 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
         jp[i] = &jobs[i];
     }
     if (n > 1) NQ_HIP(h0, hipStreamSynchronize(lane_s[1]));          // every prepare has been issued: join before the merge launch
+    (void) hipEventRecord(h0->bev[1], lane_s[0]);
     int rc = merge_launch(h0, jp.data(), n);
     if (rc) return rc;
+    (void) hipEventRecord(h0->bev[2], lane_s[0]);
     // behind the merge launch everything runs on lane 0 again: two dither kernels side by side would only slow each other down
     for (int i = 0; i < n; ++i) { hs[i]->stream = lane_s[0]; hs[i]->sc = lane_sc[0]; }
     for (int i = 0; i < n; ++i) if (jobs[i].merge) rec(hs[i], 4);
@@ -1085,8 +1116,10 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
                            d_out_index ? d_out_index[i] : nullptr);
         if (rc) return fail_from(hs[i], rc);
     }
+    (void) hipEventRecord(h0->bev[3], lane_s[0]);
     NQ_HIP(h0, hipStreamSynchronize(lane_s[0]));
     for (int i = 0; i < n; ++i) finish_timing(hs[i]);
+    finish_batch_timing(h0);
     return NQ_OK;
 }
 
@@ -1147,6 +1180,7 @@ int nq_convert_batch(nq_handle* const* hs, int n, const uint32_t* const* argb, c
     };
     std::vector<PaletteJob> jobs(n);
     std::vector<const PaletteJob*> jp(n);
+    (void) hipEventRecord(h0->bev[0], h0->stream);
     for (int i = 0; i < n; ++i) {
         int rc = upload_until(i + 2);
         if (rc) return rc;
@@ -1156,8 +1190,10 @@ int nq_convert_batch(nq_handle* const* hs, int n, const uint32_t* const* argb, c
         if (rc) return fail_from(hs[i], rc);
         jp[i] = &jobs[i];
     }
+    (void) hipEventRecord(h0->bev[1], h0->stream);
     int rc = merge_launch(h0, jp.data(), n);
     if (rc) return rc;
+    (void) hipEventRecord(h0->bev[2], h0->stream);
     for (int i = 0; i < n; ++i) if (jobs[i].merge) rec(hs[i], 4);
     for (int i = 0; i < n; ++i) {
         uint32_t* pal = out_palettes + (size_t) i * palette_stride;
@@ -1178,9 +1214,11 @@ int nq_convert_batch(nq_handle* const* hs, int n, const uint32_t* const* argb, c
             NQ_HIP(h0, hipMemcpyAsync(out_index[i], h0->ring_index[r].p, px * sizeof(uint16_t), hipMemcpyDeviceToHost, cs));
         NQ_HIP(h0, hipEventRecord(ev_dl[i], cs));
     }
+    (void) hipEventRecord(h0->bev[3], h0->stream);
     NQ_HIP(h0, hipStreamSynchronize(h0->stream));
     NQ_HIP(h0, hipStreamSynchronize(cs));
     for (int i = 0; i < n; ++i) finish_timing(hs[i]);
+    finish_batch_timing(h0);
     return NQ_OK;
 }
 

@@ -771,7 +771,7 @@ static const int8_t h_blue_fast[4096] = {
 #include "../../include/nq_blue_noise_64x64.inc"
 };
 void upload_tables_fast(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s) {
-    static ConstTables t;     // host staging must outlive the async copy
+    ConstTables t;            // (the copy below is waited for; g_tab is per device: every handle uploads to its own device)
     for (int i = 0; i < 256; ++i) t.gamma[i] = gamma[i];
     t.exp1_5 = exp1_5; t.exp1_75 = exp1_75;
     for (int i = 0; i < 4096; ++i) t.blue[i] = h_blue_fast[i];
@@ -793,6 +793,11 @@ bool gilbert_fast_eligible(const DevParams& P, const GilbertConsts& G, const Til
            fast_weights_match(G.weights) && lv.closest && lv.nearest && P.ratio >= 0 && tilepx >= 1 && tilepx <= 1024 &&
            fast_lds_bytes(tilepx, fast_stride_bytes(tilepx)) <= 160 * 1024 - 512;
 }
+// the packed list records every specialised kernel reads (the ABI calls this right behind the list builders, in front of the stage
+// event of the per-pixel pass)
+void launch_pack_lists(const ListsView& lv, void* d_packed, hipStream_t s) {
+    hipLaunchKernelGGL(pack_lists_kernel, dim3(65536 / 256), dim3(256), 0, s, to_lists_fast(lv), (uint4*) d_packed, (uint4*) d_packed + 2 * 65536);
+}
 static FastArgs fast_args(const DevParams& P, const ListsView& lv, void* d_packed, hipStream_t s) {
     FastArgs F;
     std::memset(&F, 0, sizeof F);
@@ -805,12 +810,12 @@ static FastArgs fast_args(const DevParams& P, const ListsView& lv, void* d_packe
     F.qc = (float) (P.PB * (1 - P.ratio) + P.ratio * sq[2]);
     F.packed = (const uint4*) d_packed;
     F.cont = F.packed + 2 * 65536;
-    hipLaunchKernelGGL(pack_lists_kernel, dim3(65536 / 256), dim3(256), 0, s, to_lists_fast(lv), (uint4*) d_packed, (uint4*) d_packed + 2 * 65536);
+    (void) lv; (void) s;
     return F;
 }
-void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
-                         const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
-                         int* d_failed, void* d_packed, hipStream_t s) {
+hipError_t launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
+                               const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
+                               int* d_failed, void* d_packed, hipStream_t s) {
     const int ntiles = T.tiles_x * T.tiles_y;
     const int tilepx = T.tile_w * T.tile_h;
     FastArgs F = fast_args(P, lv, d_packed, s);
@@ -822,16 +827,19 @@ void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileG
     if (const char* e = std::getenv("NQ_FAST_DEBUG")) F.debug = std::atoi(e);
 #endif
     F.vecOut = (T.tile_w % 4 == 0) && (T.width % 4 == 0) && ((uintptr_t) d_index % 8 == 0) && (!d_argb || (uintptr_t) d_argb % 16 == 0);
-    (void) hipMemsetAsync(d_failed, 0, sizeof(int), s);
+    hipError_t e = hipMemsetAsync(d_failed, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
     const size_t lds = fast_lds_bytes(tilepx, F.strideBytes);
     const int grid = (ntiles + 255) / 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void*) gilbert_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_set = true;
+    if (lds > 64 * 1024) {
+        // more than 64 KB of dynamic LDS (16x16 tiles) needs the opt-in.  The attribute belongs to the function ON THE CURRENT DEVICE, so it
+        // is set at every such launch (a host-side call, no process-wide flag: handles of several devices and threads stay independent)
+        e = hipFuncSetAttribute((const void*) gilbert_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((gilbert_fast_kernel<2>), dim3(grid), dim3(256), lds, s, P, G, T, to_lists_fast(lv), F, d_pixels, d_saliency, d_palette,
                        seed, d_index, d_argb);
+    return hipGetLastError();
 }
 
 // the lookups alone (nq_nearest_index, nq_closest_tuple, LOOKUP_ONLY) through the same device functions

@@ -77,10 +77,13 @@ void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& 
                     const int* d_tile_list, hipStream_t s);
 // nq_dither_fast.hip: the specialised kernel for LAB, 32 < K <= 256, no semi-transparency, DITHER_MAX 25, tiled
 bool gilbert_fast_eligible(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv);
-void launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
-                         const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
-                         int* d_failed /* int[1 + tiles] */, void* d_packed /* 65536 x 64 bytes */, hipStream_t s);
+hipError_t launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
+                               const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
+                               int* d_failed /* int[1 + tiles] */, void* d_packed /* 65536 x 64 bytes */, hipStream_t s);
 bool fast_lookup_eligible(const DevParams& P, const ListsView& lv);
+// packs the two lists of every colour cell into the 32-byte records (+ continuations) the specialised kernels read; must follow
+// launch_build_lists on the same stream whenever fast_lookup_eligible() holds
+void launch_pack_lists(const ListsView& lv, void* d_packed, hipStream_t s);
 void launch_fast_nearest_index(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_colors, int64_t M,
                                short* d_out, hipStream_t s);
 void launch_fast_closest_tuple(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_colors, int64_t M,

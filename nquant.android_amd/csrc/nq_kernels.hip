@@ -18,7 +18,7 @@ static const int8_t h_blue[4096] = {
 };
 
 void upload_tables(const double gamma[256], double exp1_5, double exp1_75, hipStream_t s) {
-    static ConstTables t;     // host staging must outlive the async copy
+    ConstTables t;            // (the copy below is waited for; g_tab is per device: every handle uploads to its own device)
     for (int i = 0; i < 256; ++i) t.gamma[i] = gamma[i];
     t.exp1_5 = exp1_5; t.exp1_75 = exp1_75;
     for (int i = 0; i < 4096; ++i) t.blue[i] = h_blue[i];

@@ -48,20 +48,24 @@ def reduce_scan(scan3, group=None):
 def gather_histograms(hist, group=None):
     """hist = f64[65536*5] partial of this band -> f64[world, 65536*5] in band (= rank) order on every rank."""
     world = dist.get_world_size(group)
-    on_gpu = hist.is_cuda
-    backend = dist.get_backend(group)
-    src = hist.contiguous()
-    if on_gpu and backend != "nccl":            # gloo in the tests: stage through the host
-        src = src.cpu()
+    src = hist.contiguous().to(_collective_device(group))
     parts = [torch.empty_like(src) for _ in range(world)]
     dist.all_gather(parts, src, group=group)
-    out = torch.stack(parts)
-    return out.to(hist.device) if on_gpu else out
+    return torch.stack(parts).to(hist.device)
+
+
+def _collective_device(group=None):
+    """Device the tensors of a collective must live on: RCCL ("nccl") only moves device memory -- a CPU tensor handed to it raises
+    "No backend type associated with device type cpu" --, gloo (CPU tests) only host memory."""
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
 def _gather_small(t, group=None):
+    """All-gather of a small tensor (any device) -> CPU tensor [world, ...], staged on the device the backend needs."""
     world = dist.get_world_size(group)
-    src = t.cpu() if (t.is_cuda and dist.get_backend(group) != "nccl") else t
+    src = t.to(_collective_device(group)).contiguous()
     parts = [torch.empty_like(src) for _ in range(world)]
     dist.all_gather(parts, src, group=group)
     return torch.stack(parts).cpu()
@@ -98,8 +102,8 @@ def merge_distinct(mine, cap, group=None):
     return out if len(out) <= cap else None
 
 
-def max_over_ranks(seconds, device="cpu", group=None):
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+def max_over_ranks(seconds, device=None, group=None):
+    t = torch.tensor([seconds], dtype=torch.float64, device=_collective_device(group) if device is None else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
@@ -115,8 +119,7 @@ def image_distinct_count(q, d_band, n, device, group=None, cap_other=65536):
     if n > 0:
         q._check(q._L.nq_band_color_presence_device(q._h, C.c_void_p(d_band.data_ptr()), n, C.c_void_p(presence.data_ptr()), cap_other,
                                                     C.byref(cnt), other.ctypes.data))
-    backend = dist.get_backend(group)
-    red = presence if (backend == "nccl" or not presence.is_cuda) else presence.cpu()
+    red = presence.to(_collective_device(group))
     dist.all_reduce(red, op=dist.ReduceOp.MAX, group=group)
     opaque = int(torch.count_nonzero(red))
     t = torch.full((cap_other + 1,), -1, dtype=torch.int64)

@@ -230,6 +230,20 @@ float nqo_ciede2000(const float* l1, const float* l2) {
     float rt = R_T(bc, bh, dC, dH);
     return (float) (sqr((double) dL) + sqr((double) dC) + sqr((double) dH) + rt);
 }
+/* the four CIEDE2000 terms of n pairs {L1, A1, B1, L2, A2, B2} exactly as find_nn obtains them (NQ/PnnLABQuantizer.java:93-110 calls the
+ * four functions above in this order): out4[4 i + 0..3] = L', C', H' (each already divided by k S), R_T.  Checker of the GPU's
+ * branch-free evaluation (nq_selftest_ciede). */
+void nqo_ciede_terms(const float* pairs, int64_t n, float* out4) {
+    for (int64_t i = 0; i < n; ++i) {
+        const float* q = pairs + 6 * i;
+        Lab lab1 = {255, q[1], q[2], q[0]}, lab2 = {255, q[4], q[5], q[3]};
+        double a1, a2, c1, c2, bc, bh;
+        out4[4 * i + 0] = L_prime_div_k_L_S_L(lab1, lab2);
+        out4[4 * i + 1] = C_prime_div_k_L_S_L(lab1, lab2, &a1, &a2, &c1, &c2);
+        out4[4 * i + 2] = H_prime_div_k_L_S_L(lab1, lab2, a1, a2, c1, c2, &bc, &bh);
+        out4[4 * i + 3] = R_T(bc, bh, out4[4 * i + 1], out4[4 * i + 2]);
+    }
+}
 /* :215-227 */
 static double color2Y(int32_t c) {
     double sr = gammaToLinear(c_red(c)), sg = gammaToLinear(c_green(c)), sb = gammaToLinear(c_blue(c));

@@ -99,6 +99,7 @@ int32_t nqo_get_color_index(int32_t c, int hasSemiTransparency, int hasTranspare
 void    nqo_rgb2lab(int32_t c, float* out_alpha_L_A_B);          /* NQ/CIELABConvertor.java:58-69 + ColorUtils.colorToLAB */
 int32_t nqo_lab2rgb(float alpha, float L, float A, float B);     /* :77-80 + ColorUtils.LABToColor */
 float   nqo_ciede2000(const float* lab1_L_A_B, const float* lab2_L_A_B); /* :201-213 (squared deltaE00) */
+void    nqo_ciede_terms(const float* pairs6, int64_t n, float* out4);   /* L', C', H', R_T per pair, as find_nn obtains them (:93-110 of PnnLABQuantizer) */
 double  nqo_y_diff(int32_t c1, int32_t c2);                      /* :215-227 */
 double  nqo_u_diff(int32_t c1, int32_t c2);                      /* :229-238 */
 int32_t nqo_blue_diffuse(int32_t pixel, int32_t qPixel, float weight, float strength, int x, int y); /* NQ/BlueNoise.java:180-197 */

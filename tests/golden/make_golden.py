@@ -38,6 +38,28 @@ PALETTE_CASES = {
 }
 
 
+# BASELINE cfg 2 end to end: 1024x1024 uniform random opaque RGB, seed 2 (all 65 536 bins occupied -> isNano), PnnLABQuantizer, 256
+# colours, no diffusion: the palette of the image's OWN pnnquan and the per-pixel nearestColorIndex map (cache-miss semantics =
+# MODE_LOOKUP_ONLY).  The fixture holds the palette, the scalars, the SHA-256 of the uint16 index map and every 61st index.
+LOOKUP_CASES = {
+    "cfg2_lab256_lookup_uniform_1024x1024": dict(kind=1, K=256, img=lambda: synth.uniform_rgb(1024, 1024, 2), stride=61),
+}
+
+
+def run_lookup_case(c):
+    import hashlib
+    img = c["img"]()
+    q = O.OracleQuantizer(c["kind"], img)
+    q.prescan(c["K"])
+    pal = q.pnnquan(c["K"])
+    p = q.params
+    idx = q.nearest_index(pal, img.reshape(-1)).astype(np.uint16)
+    return dict(palette=pal, scalars=np.array([p.maxbins, p.isNano, p.texicab, p.quan_rt], np.int64),
+                doubles=np.array([p.ratio, p.weight], np.float64),
+                index_sha256=np.frombuffer(hashlib.sha256(idx.tobytes()).digest(), np.uint8).copy(),
+                index_sample=idx[::c["stride"]].copy(), index_histogram=np.bincount(idx, minlength=len(pal)).astype(np.int64))
+
+
 def run_palette_case(c):
     q = O.OracleQuantizer(c["kind"], c["img"]())
     q.prescan(c["K"])
@@ -66,6 +88,10 @@ if __name__ == "__main__":
         r = run_case(c)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)
         print(name, "K", len(r["palette"]), "maxbins", int(r["scalars"][6]))
+    for name, c in LOOKUP_CASES.items():
+        r = run_lookup_case(c)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)
+        print(name, "K", len(r["palette"]), "maxbins", int(r["scalars"][0]))
     for name, c in PALETTE_CASES.items():
         r = run_palette_case(c)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)

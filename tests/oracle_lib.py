@@ -62,6 +62,8 @@ def lib():
     L.nqo_lab2rgb.argtypes = [C.c_float] * 4
     L.nqo_ciede2000.restype = C.c_float
     L.nqo_ciede2000.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.nqo_ciede_terms.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.nqo_ciede_terms.restype = None
     L.nqo_y_diff.restype = C.c_double
     L.nqo_y_diff.argtypes = [C.c_int32, C.c_int32]
     L.nqo_u_diff.restype = C.c_double
@@ -228,6 +230,14 @@ def rgb2lab(c):
 def _wrap(c):
     c = int(c) & 0xFFFFFFFF
     return c - (1 << 32) if c >= (1 << 31) else c
+
+
+def ciede_terms(pairs):
+    """(n, 6) float32 {L1,A1,B1,L2,A2,B2} -> (n, 4) float32 {L', C', H', R_T} from the oracle's four CIEDE2000 functions."""
+    a = np.ascontiguousarray(pairs, np.float32).reshape(-1, 6)
+    out = np.zeros((a.shape[0], 4), np.float32)
+    lib().nqo_ciede_terms(a.ctypes.data, a.shape[0], out.ctypes.data)
+    return out
 
 
 def ciede2000_sq(lab1, lab2):

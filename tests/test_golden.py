@@ -81,3 +81,33 @@ def test_gpu_rgb_palette_does_not_depend_on_the_assumed_error_cap(nq, name, thet
     assert st["chunks"] > 0                       # the pruned scan ran
     if theta == "1.0":
         assert st["overflows"] > 0                # ... and its fallback
+
+
+@pytest.mark.parametrize("name", sorted(mg.LOOKUP_CASES))
+def test_oracle_reproduces_golden_lookup(name):
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    got = mg.run_lookup_case(mg.LOOKUP_CASES[name])
+    for k in ("palette", "scalars", "doubles", "index_sha256", "index_sample", "index_histogram"):
+        assert (got[k] == want[k]).all(), (name, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(mg.LOOKUP_CASES))
+def test_gpu_cfg2_end_to_end_lookup_only(nq, name):
+    """BASELINE cfg 2 end to end through nq_convert(..., LOOKUP_ONLY): the image's own 65 536-bin pnnquan (palette + scalars == golden) and
+    the undithered index map (SHA-256, sample and per-entry counts == the oracle's per-pixel nearestColorIndex held by the fixture)."""
+    import hashlib
+    c = mg.LOOKUP_CASES[name]
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    img = c["img"]()
+    q = (nq.PnnLABQuantizer if c["kind"] else nq.PnnQuantizer)(img, mode=nq.MODE_LOOKUP_ONLY, seed=1)
+    out = q.convert(c["K"], False)
+    assert len(out.palette) == len(want["palette"]) and (out.palette == want["palette"]).all()
+    p = q.params
+    assert [p.maxbins, p.isNano, p.texicab, p.quan_rt] == list(want["scalars"])
+    assert (np.array([p.ratio, p.weight]) == want["doubles"]).all()
+    idx = out.index.reshape(-1).astype(np.uint16)
+    assert (idx[::c["stride"]] == want["index_sample"]).all(), "%d of the sampled indices differ" % int((idx[::c["stride"]] != want["index_sample"]).sum())
+    assert (np.bincount(idx, minlength=len(out.palette)) == want["index_histogram"]).all()
+    assert (np.frombuffer(hashlib.sha256(idx.tobytes()).digest(), np.uint8) == want["index_sha256"]).all()
+    assert (out.argb.reshape(-1) == out.palette[idx]).all()

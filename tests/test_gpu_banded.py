@@ -140,7 +140,7 @@ def _free_port():
     return port
 
 
-def _banded_worker(rank, world, port, tmp, dither):
+def _banded_worker(rank, world, port, tmp, dither, backend="gloo", give_height=True):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -150,8 +150,8 @@ def _banded_worker(rank, world, port, tmp, dither):
     import torch.distributed as dist
     import nquant.android_amd as nq
     from nquant.android_amd import parallel
-    torch.cuda.set_device(0)                   # both ranks share the one GPU of the box; the collectives run over gloo
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)                   # all ranks share the one GPU of the box; the collectives run over gloo (or RCCL, world 1)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     data = np.load(os.path.join(tmp, "case.npz"))
     img = data["img"]
     H, W = img.shape
@@ -160,7 +160,7 @@ def _banded_worker(rank, world, port, tmp, dither):
     d_out = torch.zeros(max((y1 - y0) * W, 1), dtype=torch.int32, device="cuda")
     d_idx = torch.zeros(max((y1 - y0) * W, 1), dtype=torch.int16, device="cuda")
     q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), mode=1, seed=int(data["seed"]), tile=(8, 8))
-    pal = parallel.convert_banded(q, d_band, W, y1 - y0, y0, 256, bool(dither), d_out, d_idx, image_height=H)
+    pal = parallel.convert_banded(q, d_band, W, y1 - y0, y0, 256, bool(dither), d_out, d_idx, image_height=H if give_height else None)
     torch.cuda.synchronize()
     np.savez(os.path.join(tmp, "out%d.npz" % rank), pal=pal, y0=y0, y1=y1, argb=d_out.cpu().numpy()[:(y1 - y0) * W],
              idx=d_idx.cpu().numpy().view(np.uint16)[:(y1 - y0) * W])
@@ -200,6 +200,39 @@ def test_convert_banded_two_processes_on_one_gpu(nq, oracle, tmp_path, dither, w
         if y1 > y0:
             assert (o["idx"].reshape(y1 - y0, W).astype(np.int32) == want_idx[y0:y1]).all(), "rank %d" % r
             assert (o["argb"].reshape(y1 - y0, W) == want_argb[y0:y1]).all()
+
+
+RCCL_CASES = [  # name, image, dither
+    ("lab_no_dither_k256", lambda: synth.gradient_noise(64, 128, 221), False),      # image-wide distinct-colour count: presence-table all-reduce
+    ("few_colours", lambda: synth.few_colors(64, 128, 222, 90), True),               # few-colours early return: exchange of the distinct colours
+    ("lab_dither_k256", lambda: synth.gradient_noise(64, 128, 223), True),
+]
+
+
+@pytest.mark.parametrize("name,mk,dither", RCCL_CASES)
+def test_convert_banded_under_rccl_world_1(nq, oracle, tmp_path, name, mk, dither):
+    """parallel.convert_banded with the collectives over RCCL ("nccl", a world of ONE rank on the one GPU of the box -- a one-rank RCCL
+    group already refuses host tensors, which is what the branches below used to hand it) and WITHOUT image_height (the band rows are
+    gathered): LAB dither=false K=256 (BlueNoise weight from the image-wide distinct-colour count), the few-colours early return
+    (NQ/PnnLABQuantizer.java:193-206, :511-515) and the plain dithered case, each == the oracle's banded restatement with one band."""
+    img = mk()
+    seed = 29
+    H, W = img.shape
+    np.savez(tmp_path / "case.npz", img=img, seed=seed)
+    oq = oracle.OracleQuantizer(1, img, seed=seed)
+    oq.set_bands([0])
+    oq.prescan(256)
+    want_pal = oq.pnnquan(256)
+    want_argb, want_idx = oq.dither(want_pal, dither, tile=(8, 8))
+    ctx = mp.get_context("spawn")
+    pr = ctx.Process(target=_banded_worker, args=(0, 1, _free_port(), str(tmp_path), dither, "nccl", False))
+    pr.start()
+    pr.join(300)
+    assert pr.exitcode == 0, "convert_banded failed under the nccl backend (exit code %r)" % pr.exitcode
+    o = np.load(tmp_path / "out0.npz")
+    assert len(o["pal"]) == len(want_pal) and (o["pal"] == want_pal).all()
+    assert (o["idx"].reshape(H, W).astype(np.int32) == want_idx).all()
+    assert (o["argb"].reshape(H, W) == want_argb).all()
 
 
 # ---- BASELINE cfg 4: batch of 1920x1080 frames -------------------------------------------------------------------------------

@@ -185,7 +185,7 @@ def test_big_palettes_stage_through_lds_up_to_8192_entries(nq, oracle, kind, K):
         assert e.value.status == -3
 
 
-def test_branch_free_ciede2000_equals_the_literal_functions(nq):
+def test_branch_free_ciede2000_equals_the_literal_functions(nq, oracle):
     """find_nn's exact phase evaluates deltaL', deltaC', deltaH', R_T in one branch-free pass (csrc/nq_device.h: ciede_terms_fast) and
     falls back to the literal functions (device-library pow / atan2 / sin / cos / exp) wherever a float narrowing or an angle
     comparison is too close to call.  Wherever the fast pass decides, its four floats must equal the literal ones bit for bit:
@@ -219,7 +219,60 @@ def test_branch_free_ciede2000_equals_the_literal_functions(nq):
         assert q.ciede_quad_identical.all(), "set %d: quad pass differs on %d pairs" % (k, int((q.ciede_quad_identical == 0).sum()))
         bad = (fast[dec] != lit[dec]).any(axis=1)
         assert not bad.any(), "set %d: %d of %d decided pairs differ, first %s" % (k, int(bad.sum()), int(dec.sum()), s[dec][bad][:1])
+        # ... and against the ORACLE's four functions (oracle/nq_oracle.c L_prime / C_prime / H_prime / R_T with glibc's libm, restating
+        # NQ/CIELABConvertor.java:91-194) on the same pairs: what find_nn uses on the GPU -- the fast floats where the pass decided,
+        # the literal ones elsewhere -- must be the oracle's floats bit for bit (the claim "every ulp-accurate implementation narrows to
+        # the same float", checked directly instead of through palette equality)
+        want = oracle.ciede_terms(s.astype(np.float32)).view(np.uint32)
+        used = np.where(dec[:, None], fast, lit)
+        hard = (used != want).any(axis=1)
+        assert not hard.any(), "set %d: %d of %d pairs differ from the oracle (%d where the fast pass decided), first %s -> gpu %s oracle %s" % (
+            k, int(hard.sum()), len(s), int((hard & dec).sum()), s[hard][:1], used[hard][:1], want[hard][:1])
         decided_total += int(dec.sum())
         if k != 4:                          # hues 1e-6 rad apart: the sine of the half difference loses all relative accuracy -> always literal
             assert dec.mean() > 0.95, (k, float(dec.mean()))
     assert decided_total > 0.8 * n * (len(sets) - 1)
+
+
+def test_two_threads_two_handles_on_one_device(nq, oracle):
+    """Distinct handles are independent (include/nquant_abi.h, "Threads and devices"): two host threads, each with its own handle on
+    device 0 and its own stream, convert different images at the same time -- with 16x16 tiles, the configuration whose dither launch
+    needs the > 64 KB dynamic-LDS attribute (set per launch on the current device, no process-wide flag) -- and both results equal the
+    oracle's."""
+    import threading
+    import torch
+    imgs = [synth.uniform_rgb(192, 160, 401), synth.uniform_rgb(176, 176, 402)]
+    seeds = [17, 18]
+    want = []
+    for img, seed in zip(imgs, seeds):
+        oq = oracle.OracleQuantizer(1, img, seed=seed)
+        oq.prescan(256)
+        pal = oq.pnnquan(256)
+        argb, idx = oq.dither(pal, True, tile=(16, 16))
+        want.append((pal, argb, idx))
+    got = [None, None]
+    errs = []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream()
+            for _ in range(3):
+                q = nq.PnnLABQuantizer(imgs[k], mode=nq.MODE_PARALLEL_TILED, seed=seeds[k], tile=(16, 16))
+                q.set_stream(st.cuda_stream)
+                out = q.convert(256, True)
+                fast = q.dither_path()[0]
+                got[k] = (out, fast)
+                q.close()
+        except Exception as e:          # surfaced after the join
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        out, fast = got[k]
+        pal, argb, idx = want[k]
+        assert fast == 1, "the 16x16 case must run the specialised kernel"
+        assert (out.palette == pal).all() and (out.index.astype(np.int32) == idx).all() and (out.argb == argb).all()

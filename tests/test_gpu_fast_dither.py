@@ -68,6 +68,11 @@ FAST_CASES = [
     (256, True, lambda: synth.gradient_noise(50, 46, 142), (8, 8), 0.0115),        # image width not a multiple of 4
     (256, True, lambda: synth.uniform_rgb(192, 160, 137), (8, 8), None),           # 30 720 pixels, ~24 000 bins: the rung by itself
     (256, False, lambda: synth.uniform_rgb(256, 200, 148), (4, 4), None),
+    # further natural cases (nothing injected): 19 819 bins of 1-5-5-5 keys WITH alpha-0 pixels (tiles are handed back to the generic
+    # kernel); K = 100 / 21 403 bins (saliencies from the pnnquan pass, nMaxColors < 128); K = 128 / 26 544 bins, ragged 4x4 tiles
+    (256, True, lambda: synth.with_alpha(synth.uniform_rgb(192, 160, 301), 301, p_transparent=0.01, p_semi=0.0), (8, 8), None),
+    (100, True, lambda: synth.gradient_noise(320, 240, 302, noise=40), (8, 8), None),
+    (128, False, lambda: synth.gradient_noise(398, 299, 303, noise=48), None, None),
     (256, True, lambda: synth.few_colors(96, 96, 143, 3000), (8, 8), None),        # sorted-by-yDiff queue: generic kernel only
     (16, True, lambda: synth.gradient_noise(64, 64, 144), (8, 8), None),           # K <= 32: generic kernel only
 ]
@@ -97,6 +102,8 @@ def test_bench_tile_shapes_bit_exact_vs_oracle(nq, oracle, K, dither, mk, tile, 
         got_argb, got_idx = gq.dither(pal, dither)
         ran_fast, handed_back = gq.dither_path()
         assert ran_fast == (1 if (fast and expect_fast) else 0), (fast, ran_fast, op.weight)
+        if fast and expect_fast and (img.view(np.uint32) >> 24 == 0).any():
+            assert handed_back > 0, "an image with alpha-0 pixels must hand tiles back to the generic kernel"
         bad = (got_idx.astype(np.int32) != want_idx).sum()
         assert bad == 0, "fast=%d: index mismatches %d of %d (tiles handed back: %d)" % (fast, bad, want_idx.size, handed_back)
         assert (got_argb != want_argb).sum() == 0
