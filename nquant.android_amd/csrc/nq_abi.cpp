@@ -182,6 +182,8 @@ struct nq_handle {
     hipStream_t copy_stream = nullptr;
     hipStream_t lane_stream = nullptr;  // second lane of the batch entry points
     long long merge_stats[16] = {0};
+    long long team_stats[8] = {0};    // merge teams: {work records published, results used, timed-out waits, ticks waited, helpers, still speculating}
+    DevBuf<unsigned long long> team;  // 256 u64 of hand-off words of this handle's merge team
     hipEvent_t bev[4] = {nullptr};    // batch entry points: phase boundaries on the launch stream (first handle of the batch)
     float batch_phase_ms[4] = {0};
     bool ext_distinct_valid = false, ext_distinct_many = false;  // nq_set_distinct: image-wide distinct colours (first-occurrence order) of the split pipeline
@@ -220,7 +222,7 @@ int use_device(nq_handle* h) {
         upload_tables(gamma, std::exp(1.5), std::exp(1.75), h->stream);
         upload_tables_fast(gamma, std::exp(1.5), std::exp(1.75), h->stream);
         NQ_HIP(h, hipGetLastError());
-        NQ_HIP(h, h->d_scalars.reserve(40));
+        NQ_HIP(h, h->d_scalars.reserve(48));
         NQ_HIP(h, h->d_ints.reserve(8 + 64));
         NQ_HIP(h, h->d_bincache.reserve(65536));
         for (auto& e : h->ev) NQ_HIP(h, hipEventCreate(&e));
@@ -316,6 +318,7 @@ int reserve_palette_ws(nq_handle* h, int64_t n) {
     NQ_HIP(h, h->live3.reserve((size_t) 3 * 65536));
     NQ_HIP(h, h->scan_f.reserve((size_t) 2 * 10 * 65536 + 256)); NQ_HIP(h, h->scan_i.reserve((size_t) 2 * 65536));
     NQ_HIP(h, h->scan_box.reserve((size_t) 1024 * 8));
+    NQ_HIP(h, h->team.reserve(256));
     return NQ_OK;
 }
 
@@ -499,7 +502,8 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
     job->merge = true;
     job->mj.np = np; job->mj.B = B; job->mj.maxbins = maxbins; job->mj.extbins = extbins;
     job->mj.heap = h->heap.p; job->mj.live3 = h->live3.p; job->mj.scan_f = h->scan_f.p; job->mj.scan_i = h->scan_i.p; job->mj.scan_box = h->scan_box.p;
-    job->mj.stats = h->d_scalars.p + 4;
+    job->mj.stats = h->d_scalars.p + 4;       // [4..19] the 16 counters of nq_get_merge_stats, [24..31] the team counters
+    job->mj.team = h->team.p; job->mj.helpers = 0;
     job->plen = extbins > 0 ? nMaxColors : maxbins;
     // the merge workgroup also fills the palette (P10)
     NQ_HIP(h, h->d_palette.reserve((size_t) std::max(job->plen, 2)));
@@ -518,11 +522,18 @@ int merge_launch(nq_handle* owner, const PaletteJob* const* jobs, int n) {
         if (pass == 1) n_lab = (int) host.size();
     }
     if (host.empty()) return NQ_OK;
+    // merge teams: when the LAB loops of this call leave CUs free (one 512-thread workgroup per CU), every loop gets helper workgroups
+    // that evaluate find_nn speculatively (nq_merge.inc); their hand-off words start zeroed
+    const int helpers = nq::merge_team_helpers(n_lab, (int) host.size());
+    for (int i = 0; i < n_lab; ++i) {
+        host[i].helpers = helpers;
+        if (helpers > 0) NQ_HIP(owner, hipMemsetAsync(host[i].team, 0, 256 * sizeof(unsigned long long), owner->stream));
+    }
     NQ_HIP(owner, owner->d_jobs.reserve(host.size()));
     NQ_HIP(owner, hipMemcpyAsync(owner->d_jobs.p, host.data(), host.size() * sizeof(nq::MergeJob), hipMemcpyHostToDevice, owner->stream));
     NQ_HIP(owner, hipStreamSynchronize(owner->stream));    // `host` goes out of scope
-    launch_merge(1, owner->d_jobs.p, n_lab, (int) host.size(), owner->stream);
-    launch_merge(0, owner->d_jobs.p + n_lab, (int) host.size() - n_lab, (int) host.size(), owner->stream);
+    launch_merge(1, owner->d_jobs.p, n_lab, (int) host.size(), helpers, owner->stream);
+    launch_merge(0, owner->d_jobs.p + n_lab, (int) host.size() - n_lab, (int) host.size(), 0, owner->stream);
     NQ_HIP(owner, hipGetLastError());
     return NQ_OK;
 }
@@ -537,6 +548,7 @@ int palette_finish(nq_handle* h, const PaletteJob& job, uint32_t* out_palette, i
     NQ_HIP(h, hipMemcpyAsync(out_palette, h->d_palette.p, plen * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipMemcpyAsync(h->merge_stats, h->d_scalars.p + 4, sizeof h->merge_stats, hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipMemcpyAsync(h->team_stats, h->d_scalars.p + 24, sizeof h->team_stats, hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
     NQ_HIP(h, hipGetLastError());
     if (h->merge_stats[14]) NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "merge loop stopped by its watchdog (more than maxbins^2/2 find_nn calls, 240 s of wall clock, or an empty heap)");
@@ -918,6 +930,11 @@ int nq_set_params(nq_handle* h, const nq_params* in) {
 int nq_get_merge_stats(const nq_handle* h, int64_t* out8) {
     if (!h || !out8) return NQ_ERR_INVALID;
     std::memcpy(out8, h->merge_stats, 16 * sizeof(long long));
+    return NQ_OK;
+}
+int nq_get_team_stats(const nq_handle* h, int64_t* out8) {
+    if (!h || !out8) return NQ_ERR_INVALID;
+    std::memcpy(out8, h->team_stats, sizeof h->team_stats);
     return NQ_OK;
 }
 int nq_get_batch_phase_ms(const nq_handle* h0, float* out4) {

@@ -149,10 +149,15 @@ struct MergeJob {
     float* scan_box;            // float[1024 * 8]: bounding boxes of the 64-position blocks of the LAB scan arrays
     long long* stats;
     int plen; int* palette; int* status;   // P10 runs at the end of the merge workgroup: palette[plen], status |= 1 where Java throws
+    // merge teams (launch_merge decides): 256 u64 of zeroed device memory per job for the work records / results of the helpers
+    unsigned long long* team; int helpers;
 };
 // d_jobs: n jobs of one kind in device memory, one workgroup per job.  n_in_flight = merge loops expected to run at the same
 // time on the device (the whole batch): <= 256 -> 512-thread workgroups, one per CU; <= 512 -> 256 threads, two per CU;
-// more -> 128 threads, four per CU
-void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, hipStream_t s);
+// more -> 128 threads, four per CU.  helpers > 0 (LAB, 512-thread variant only; every job's `team` area zeroed and `helpers` set to the
+// same number): the grid holds 1 + helpers workgroups per job (merge teams, nq_merge.inc).
+void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int helpers, hipStream_t s);
+// helpers launch_merge would use for n LAB jobs that are alone on the device (0..7; NQ_MERGE_HELPERS overrides)
+int merge_team_helpers(int n_lab_jobs, int n_in_flight);
 
 } // namespace nq

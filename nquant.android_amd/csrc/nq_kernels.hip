@@ -239,20 +239,40 @@ void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, float* 
 }
 // one workgroup per job; the workgroup size follows the number of jobs in flight (nq_merge.inc)
 template <typename K>
-static void launch_merge_variant(K kernel, size_t dyn, int threads, const MergeJob* d_jobs, int n, hipStream_t s) {
+static void launch_merge_variant(K kernel, size_t dyn, int threads, const MergeJob* d_jobs, int n, hipStream_t s, int n_pad = 0, int roles = 1) {
     (void) hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
-    hipLaunchKernelGGL(kernel, dim3(n), dim3(threads), dyn, s, d_jobs);
+    hipLaunchKernelGGL(kernel, dim3(roles > 1 ? n_pad * roles : n), dim3(threads), dyn, s, d_jobs, n, n_pad);
 }
-void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, hipStream_t s) {
-    if (n <= 0) return;
+static int merge_threads_for(int n_in_flight) {
     if (const char* f = std::getenv("NQ_MERGE_THREADS")) {       // tests: force one variant (512, 256 or 128)
         const int t = std::atoi(f);
-        n_in_flight = t == 128 ? 1024 : t == 256 ? 512 : t == 512 ? 1 : n_in_flight;
+        if (t == 128 || t == 256 || t == 512) return t;
     }
-    if (n_in_flight <= 256) {
-        if (kind == 1) launch_merge_variant(m512::merge_kernel<1>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
+    return n_in_flight <= 256 ? 512 : n_in_flight <= 512 ? 256 : 128;
+}
+int merge_team_helpers(int n_lab_jobs, int n_in_flight) {
+    if (n_lab_jobs <= 0 || merge_threads_for(n_in_flight) != 512) return 0;
+    const int n_pad = (n_lab_jobs + 7) / 8 * 8;
+    int h = 256 / n_pad - 1;                       // one 512-thread workgroup per CU, 256 CUs
+    if (h > 7) h = 7;
+    if (h < 0) h = 0;
+    if (const char* f = std::getenv("NQ_MERGE_HELPERS")) {       // tests / measurements: 0 = the single-workgroup loop
+        const int t = std::atoi(f);
+        if (t >= 0 && t <= 7) h = t;
+    }
+    return h;
+}
+void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int helpers, hipStream_t s) {
+    if (n <= 0) return;
+    const int threads = merge_threads_for(n_in_flight);
+    if (threads == 512) {
+        if (kind == 1 && helpers > 0) {
+            const int n_pad = (n + 7) / 8 * 8;
+            launch_merge_variant(m512::merge_kernel<1, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
+        }
+        else if (kind == 1) launch_merge_variant(m512::merge_kernel<1>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
         else launch_merge_variant(m512::merge_kernel<0>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
-    } else if (n_in_flight <= 512) {
+    } else if (threads == 256) {
         if (kind == 1) launch_merge_variant(m256::merge_kernel<1>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
         else launch_merge_variant(m256::merge_kernel<0>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
     } else {

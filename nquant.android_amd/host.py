@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "nq_set_params", "nq_convert", "nq_convert_device", "nq_convert_batch_device", "nq_convert_batch", "nq_pnnquan", "nq_pnnquan_device", "nq_dither",
     "nq_dither_device", "nq_nearest_index", "nq_closest_tuple", "nq_band_scan_device", "nq_set_scan",
     "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_band_distinct_device", "nq_set_distinct", "nq_get_stage_ms", "nq_get_merge_stats",
-    "nq_get_dither_path", "nq_get_batch_phase_ms", "nq_set_band", "nq_band_color_presence_device", "nq_gilbert_dither", "nq_bluenoise_dither", "nq_selftest_ciede",
+    "nq_get_dither_path", "nq_get_batch_phase_ms", "nq_get_team_stats", "nq_set_band", "nq_band_color_presence_device", "nq_gilbert_dither", "nq_bluenoise_dither", "nq_selftest_ciede",
 ]
 OPT_CELL_LISTS, OPT_FAST_DITHER = 1, 2
 
@@ -118,6 +118,7 @@ def load_library():
     L.nq_get_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.nq_get_merge_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.nq_get_batch_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.nq_get_team_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.nq_get_dither_path.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.nq_set_band.argtypes = [vp, i32, i32]
     L.nq_selftest_ciede.argtypes = [vp, vp, i64, vp]
@@ -223,6 +224,12 @@ class PnnQuantizer:
         a = (C.c_float * 8)()
         self._check(self._L.nq_get_stage_ms(self._h, a))
         return dict(zip(STAGES, list(a)))
+
+    def team_stats(self):
+        """Counters of the last merge loop's team of helper workgroups (nq_get_team_stats)."""
+        a = (C.c_int64 * 8)()
+        self._check(self._L.nq_get_team_stats(self._h, a))
+        return dict(zip(["published", "used", "timeouts", "wait_ticks_100MHz", "helpers", "speculating_at_end"], list(a)[:6]))
 
     def batch_phase_ms(self):
         """Phases of the last batch call this quantizer was the FIRST handle of: {prepare, merge, finish, total} in ms (nq_get_batch_phase_ms)."""

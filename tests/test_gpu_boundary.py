@@ -220,14 +220,30 @@ def test_branch_free_ciede2000_equals_the_literal_functions(nq, oracle):
         bad = (fast[dec] != lit[dec]).any(axis=1)
         assert not bad.any(), "set %d: %d of %d decided pairs differ, first %s" % (k, int(bad.sum()), int(dec.sum()), s[dec][bad][:1])
         # ... and against the ORACLE's four functions (oracle/nq_oracle.c L_prime / C_prime / H_prime / R_T with glibc's libm, restating
-        # NQ/CIELABConvertor.java:91-194) on the same pairs: what find_nn uses on the GPU -- the fast floats where the pass decided,
-        # the literal ones elsewhere -- must be the oracle's floats bit for bit (the claim "every ulp-accurate implementation narrows to
-        # the same float", checked directly instead of through palette equality)
+        # NQ/CIELABConvertor.java:91-194) on the same pairs, i.e. what find_nn really uses on the GPU (the fast floats where the pass
+        # decided, the literal ones elsewhere) against the oracle's floats:
+        #  * wherever the fast pass DECIDED the floats must be the oracle's bit for bit (its acceptance margins claim exactly that:
+        #    any ulp-accurate libm narrows to the same float there);
+        #  * where it declined, the device library's pow / atan2 / sin / cos / exp stand against glibc's.  Both are accurate to about an
+        #    ulp of the double, but deltaH' = 2 sqrt(C1' C2') sin((h2' - h1') / 2) amplifies an ulp of atan2 when the two hues nearly
+        #    cancel (the very reason the pass declines), so a float may move by a few ulps -- Java's own Math.atan2 is libm dependent
+        #    in the same way (HotSpot intrinsic / fdlibm / bionic).  Measured on these 3 M pairs: one pair, 2 ulps in H' and R_T.
         want = oracle.ciede_terms(s.astype(np.float32)).view(np.uint32)
         used = np.where(dec[:, None], fast, lit)
-        hard = (used != want).any(axis=1)
-        assert not hard.any(), "set %d: %d of %d pairs differ from the oracle (%d where the fast pass decided), first %s -> gpu %s oracle %s" % (
-            k, int(hard.sum()), len(s), int((hard & dec).sum()), s[hard][:1], used[hard][:1], want[hard][:1])
+        diff = used != want
+        hard = diff.any(axis=1) & dec
+        assert not hard.any(), "set %d: %d of %d DECIDED pairs differ from the oracle, first %s -> gpu %s oracle %s" % (
+            k, int(hard.sum()), int(dec.sum()), s[hard][:1], used[hard][:1], want[hard][:1])
+        soft = diff.any(axis=1) & ~dec
+        if soft.any():
+            # undecided pairs: H' (and R_T, which multiplies it) may differ in the last places of a SMALL number -- the error of the two
+            # atan2 implementations (~1e-16 rad) over a hue difference of 1e-6 rad and less (set 4) is a relative 1e-10 of the double but
+            # after the cancellation up to ~1e-3 of H' itself, on an H' of ~1e-4 that enters a sum of order 1 squared: absolute bound
+            gu, wu = used[soft].view(np.float32).astype(np.float64), want[soft].view(np.float32).astype(np.float64)
+            assert (np.abs(gu - wu) <= 1e-6 * np.maximum(1.0, np.abs(wu))).all(), "set %d: undecided pairs off by %g" % (k, float(np.abs(gu - wu).max()))
+            assert not diff[soft][:, :2].any(), "L' and C' hold no cancelling difference: they must agree"
+            if k != 4:
+                assert soft.sum() <= 1e-4 * len(s), "set %d: %d undecided pairs differ from the oracle" % (k, int(soft.sum()))
         decided_total += int(dec.sum())
         if k != 4:                          # hues 1e-6 rad apart: the sine of the half difference loses all relative accuracy -> always literal
             assert dec.mean() > 0.95, (k, float(dec.mean()))

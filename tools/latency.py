@@ -23,3 +23,8 @@ print("finds %d merges %d | per find us: total %.2f ctrl %.2f bound %.2f (seed %
     st["seed_round_ticks"] / n / 100, st["exact_ticks"] / n / 100, st["replay_ticks"] / n / 100, st["chunks"] / n, st["chunks_l1"] / n,
     st["chunks_l2"] / n, st["chunks_listed"] / n, st["exact_evals"] / n))
 print("overflows %d rebuilds %d ratio %.4f" % (st["overflows"], st["rebuilds"], q.params.ratio))
+ts = q.team_stats()
+print("team: helpers %d published %d used %d timeouts %d wait %.2f us per used result, speculating at end %d" % (
+    ts["helpers"], ts["published"], ts["used"], ts["timeouts"], ts["wait_ticks_100MHz"] / max(ts["used"] + ts["timeouts"], 1) / 100, ts["speculating_at_end"]))
+import hashlib
+print("palette sha", hashlib.sha256(pal.tobytes()).hexdigest()[:16])
