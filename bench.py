@@ -83,7 +83,26 @@ def measured_traffic(w, h):
     return None
 
 
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries loaded later write there too (RCCL prints a version banner to stdout when its
+    communicator starts), so file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved descriptor."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(saved, "w")
+
+
+_JSON_OUT = None
+
+
+def emit(line):
+    _JSON_OUT.write(json.dumps(line) + "\n")
+    _JSON_OUT.flush()
+
+
 def main():
+    global _JSON_OUT
+    _JSON_OUT = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="one step = one batch of --batch images through the whole hot path")
@@ -324,7 +343,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        emit(line)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -379,7 +398,7 @@ def bench_cfg4(args, nq, synth, dist, rank, local_rank, world):
     if rank == 0:
         kernel_ms = dither_ms / (args.steps * len(slots))
         achieved = BYTES_PER_PIXEL * npx / (kernel_ms * 1e-3) / 1e9
-        print(json.dumps({
+        emit(({
             "metric": "Mpixels/sec, batch of 64 x 1920x1080 RGBA -> 256-colour PnnLAB + dither, frames sharded over the GPUs",
             "value": round(args.steps * frames * npx / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
@@ -436,7 +455,7 @@ def bench_cfg5(args, nq, synth, dist, rank, local_rank, world):
         band_px = rows * W
         achieved = BYTES_PER_PIXEL * band_px / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         hist_bytes = 65536 * 5 * 8
-        print(json.dumps({
+        emit(({
             "metric": "Mpixels/sec, 16384x16384 RGBA tiled across the GPUs -> 256-colour PnnLAB%s (RCCL histogram exchange)"
                       % (", dither=false + BlueNoise post-pass" if args.no_dither else " + dither"),
             "value": round(args.steps * W * H / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,

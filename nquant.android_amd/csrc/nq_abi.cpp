@@ -182,7 +182,7 @@ struct nq_handle {
     hipStream_t copy_stream = nullptr;
     hipStream_t lane_stream = nullptr;  // second lane of the batch entry points
     long long merge_stats[16] = {0};
-    long long team_stats[8] = {0};    // merge teams: {work records published, results used, timed-out waits, ticks waited, helpers, still speculating}
+    long long team_stats[16] = {0};    // merge teams: {work records published, results used, timed-out waits, ticks waited, helpers, still speculating}
     DevBuf<unsigned long long> team;  // 256 u64 of hand-off words of this handle's merge team
     hipEvent_t bev[4] = {nullptr};    // batch entry points: phase boundaries on the launch stream (first handle of the batch)
     float batch_phase_ms[4] = {0};
@@ -222,7 +222,7 @@ int use_device(nq_handle* h) {
         upload_tables(gamma, std::exp(1.5), std::exp(1.75), h->stream);
         upload_tables_fast(gamma, std::exp(1.5), std::exp(1.75), h->stream);
         NQ_HIP(h, hipGetLastError());
-        NQ_HIP(h, h->d_scalars.reserve(48));
+        NQ_HIP(h, h->d_scalars.reserve(64));
         NQ_HIP(h, h->d_ints.reserve(8 + 64));
         NQ_HIP(h, h->d_bincache.reserve(65536));
         for (auto& e : h->ev) NQ_HIP(h, hipEventCreate(&e));
@@ -932,9 +932,9 @@ int nq_get_merge_stats(const nq_handle* h, int64_t* out8) {
     std::memcpy(out8, h->merge_stats, 16 * sizeof(long long));
     return NQ_OK;
 }
-int nq_get_team_stats(const nq_handle* h, int64_t* out8) {
-    if (!h || !out8) return NQ_ERR_INVALID;
-    std::memcpy(out8, h->team_stats, sizeof h->team_stats);
+int nq_get_team_stats(const nq_handle* h, int64_t* out16) {
+    if (!h || !out16) return NQ_ERR_INVALID;
+    std::memcpy(out16, h->team_stats, sizeof h->team_stats);
     return NQ_OK;
 }
 int nq_get_batch_phase_ms(const nq_handle* h0, float* out4) {

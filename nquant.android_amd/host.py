@@ -227,9 +227,10 @@ class PnnQuantizer:
 
     def team_stats(self):
         """Counters of the last merge loop's team of helper workgroups (nq_get_team_stats)."""
-        a = (C.c_int64 * 8)()
+        a = (C.c_int64 * 16)()
         self._check(self._L.nq_get_team_stats(self._h, a))
-        return dict(zip(["published", "used", "timeouts", "wait_ticks_100MHz", "helpers", "speculating_at_end"], list(a)[:6]))
+        return dict(zip(["published", "used", "timeouts", "wait_ticks_100MHz", "helpers", "speculating_at_end", "cache_hits_top", "cache_hits_neighbour",
+                         "sift_ticks", "merge_ticks", "top_fetch_ticks", "pops", "epilogue_ticks", "select_ticks", "sift_global_ticks"], list(a)))
 
     def batch_phase_ms(self):
         """Phases of the last batch call this quantizer was the FIRST handle of: {prepare, merge, finish, total} in ms (nq_get_batch_phase_ms)."""
