@@ -138,6 +138,7 @@ struct Scratch {
     DevBuf<int> init_cand;            // initial LAB pass: candidate lists {bin, bound}[65536][128], then the counts [65536]
     DevBuf<unsigned char> cell_lists; // closest lists, nearest lists (65536 x 32 each), then their counts (65536 each)
     DevBuf<float> saliency;           // saliency map of the image being dithered
+    DevBuf<unsigned> lookup_todo;     // LOOKUP_ONLY: {count, pixel indices the float32 pass leaves to the exact pass}
     DevBuf<unsigned> dk_a, dk_b, di_a, di_b;   // distinct-colour sort scratch
     DevBuf<unsigned char> dtmp;
     DevBuf<unsigned long long> dheads;         // {colour, first index} pairs (uint2)
@@ -638,9 +639,12 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         nq::ListsView lv;
         int rcl = prepare_lists(h, P, &lv);
         if (rcl) return rcl;
-        rec(h, 5);       // stage "dither" = the lookup kernel alone (the candidate lists are built in front of it), "bluenoise" = 0
-        if (h->use_fast_dither && fast_lookup_eligible(P, lv))
-            launch_fast_lookup_only(P, lv, h->d_palette.p, packed_lists(h), (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
+        const bool fast_lookup = h->use_fast_dither && fast_lookup_eligible(P, lv);
+        if (fast_lookup) NQ_HIP(h, h->sc->lookup_todo.reserve((size_t) n + 1));
+        rec(h, 5);       // stage "dither" = the lookup kernels alone (the candidate lists are built in front of them), "bluenoise" = 0
+        if (fast_lookup)
+            launch_fast_lookup_only(P, lv, h->d_palette.p, packed_lists(h), (const int*) d_argb, n, d_out_index, (int*) d_out_argb,
+                                    h->sc->lookup_todo.p, h->stream);
         else
             launch_lookup_only(P, h->d_palette.p, lv, (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
         rec(h, 6); rec(h, 7);

@@ -282,7 +282,8 @@ __device__ __forceinline__ FastClosest fast_closest_tuple(const FastLds& S, cons
 // nearestColorIndex (cache-miss semantics) of a visible colour for K > 32 (NQ/PnnLABQuantizer.java:369-375): argmin of
 // |dL| + sqrt(dA^2 + dB^2) over the n2 listed candidates, ties to the higher index.  float32 first (lab32_of); the exact f64 scan
 // decides when the runner-up is within 2 NQ_FAST_NEAR_EPS.
-__device__ __forceinline__ int fast_nearest(const FastLds& S, const FastLookup& X, int c, uint4 na, int n2, int cell) {
+// float32 part: the argmin and whether it is safe (runner-up more than 2 NQ_FAST_NEAR_EPS behind)
+__device__ __forceinline__ int fast_nearest32(const FastLds& S, const FastLookup& X, int c, uint4 na, int n2, int cell, bool& safe) {
     float L1, A1, B1;
     lab32_of(c, S.gamma32, L1, A1, B1);
     float d1 = 3.0e38f, d2 = 3.0e38f;
@@ -323,7 +324,13 @@ __device__ __forceinline__ int fast_nearest(const FastLds& S, const FastLookup& 
             d1 = fminf(d1, d);
         }
     }
-    if (!(d2 - d1 > 2.0f * NQ_FAST_NEAR_EPS)) k1 = fast_nearest_exact(S, c, na, X.cont + 65536 + cell, n2, X.kfirst);
+    safe = d2 - d1 > 2.0f * NQ_FAST_NEAR_EPS;
+    return k1;
+}
+__device__ __forceinline__ int fast_nearest(const FastLds& S, const FastLookup& X, int c, uint4 na, int n2, int cell) {
+    bool safe;
+    int k1 = fast_nearest32(S, X, c, na, n2, cell, safe);
+    if (!safe) k1 = fast_nearest_exact(S, c, na, X.cont + 65536 + cell, n2, X.kfirst);
     return k1;
 }
 
@@ -693,12 +700,67 @@ __global__ void __launch_bounds__(256) fast_nearest_index_kernel(DevParams P, Ce
     for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long) gridDim.x * blockDim.x)
         out[i] = (short) fast_nearest_any(P, T, X, lists, colors[i]);
 }
-__global__ void __launch_bounds__(256) fast_lookup_only_kernel(DevParams P, CellLists lists, FastArgs F, const int* __restrict__ g_palette,
-                                                               const int* __restrict__ pixels, long long N,
-                                                               unsigned short* __restrict__ out_index, int* __restrict__ out_argb) {
+// LOOKUP_ONLY in two passes.  Pass 1 is the float32 pre-selection alone -- no f64 code, no generic fallback in the kernel, so it
+// keeps a small register file (the one-pass form held 199 VGPRs = 2 wavefronts per SIMD and spent 58 % of its wavefront cycles
+// waiting) -- and appends every pixel it cannot settle (runner-up within the error bound, alpha <= 0xF, a cell without a packed list)
+// to a list; pass 2 runs the exact functions over that list.  Same results as the one-pass form.
+__global__ void __launch_bounds__(256) fast_lookup_pass1_kernel(DevParams P, FastArgs F, const int* __restrict__ g_palette,
+                                                                const int* __restrict__ pixels, long long N,
+                                                                unsigned short* __restrict__ out_index, int* __restrict__ out_argb,
+                                                                unsigned* __restrict__ todo /* [0] = count, [1..] = pixel indices */) {
+    __shared__ __align__(16) int s_argb[256];
+    __shared__ __align__(16) float4 s_lab[256];
+    __shared__ float s_gamma32[256];
+    const int tid = threadIdx.x;
+    {
+        const int c2 = tid < P.K ? g_palette[tid] : 0;
+        s_argb[tid] = c2;
+        const Lab l2 = RGB2LAB(c2);
+        s_lab[tid] = make_float4(l2.L, l2.A, l2.B, 0.f);
+        s_gamma32[tid] = (float) g_tab.gamma[tid];
+    }
+    __syncthreads();
+    FastLds S;
+    S.argb = s_argb; S.lab = s_lab; S.gamma = nullptr; S.gamma32 = s_gamma32; S.blue = nullptr; S.path = nullptr; S.tileinfo = nullptr; S.stage = nullptr;
+    FastLookup X;
+    X.packed = F.packed; X.cont = F.cont; X.qa = X.qb = X.qc = 0.f; X.wr = X.wg = X.wb = X.ratio = 0.0;
+    X.kfirst = P.hasAlpha ? 1 : 0;
+    const int lane = tid & 63;
+    const long long stride = (long long) gridDim.x * blockDim.x;
+    const long long n_round = (N + stride - 1) / stride * stride;              // whole wavefronts stay in the loop (ballot below)
+    for (long long i = (long long) blockIdx.x * blockDim.x + tid; i < n_round; i += stride) {
+        const bool in = i < N;
+        const int c = in ? pixels[i] : (int) 0xFF000000;
+        bool safe = false;
+        int k = 0;
+        if (c_alpha(c) > 0xF) {
+            const int cell = cell_of(c);
+            const uint4 na = X.packed[2 * cell + 1];
+            const int n = (int) (na.w >> 24);
+            if (n != 255) k = fast_nearest32(S, X, c, na, n, cell, safe);
+        }
+        const bool defer = in && !safe;
+        const unsigned long long dm = __ballot(defer);
+        if (dm) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&todo[0], (unsigned) __popcll(dm));
+            base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
+            if (defer) todo[1 + base + __popcll(dm & ((1ULL << lane) - 1ULL))] = (unsigned) i;
+        }
+        if (in && safe) {
+            if (out_index) out_index[i] = (unsigned short) k;
+            if (out_argb) out_argb[i] = s_argb[k];
+        }
+    }
+}
+__global__ void __launch_bounds__(256) fast_lookup_pass2_kernel(DevParams P, CellLists lists, FastArgs F, const int* __restrict__ g_palette,
+                                                                const int* __restrict__ pixels, unsigned short* __restrict__ out_index,
+                                                                int* __restrict__ out_argb, const unsigned* __restrict__ todo) {
     const FastLookupLds T = fast_stage_lookup(P, g_palette);
     const FastLookup X = fast_lookup_ctx(P, F);
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long) gridDim.x * blockDim.x) {
+    const unsigned count = todo[0];
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+        const long long i = (long long) todo[1 + t];
         const int k = fast_nearest_any(P, T, X, lists, pixels[i]);          // (nMaxColors > 32 here: no alpha-0 rewrite)
         if (out_index) out_index[i] = (unsigned short) k;
         if (out_argb) out_argb[i] = T.S.argb[k];
@@ -858,10 +920,15 @@ void launch_fast_closest_tuple(const DevParams& P, const ListsView& lv, const in
     hipLaunchKernelGGL(fast_closest_tuple_kernel, dim3(fast_grid(M)), dim3(256), 0, s, P, to_lists_fast(lv), F, d_palette, d_colors, (long long) M, d_out4);
 }
 void launch_fast_lookup_only(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_pixels, int64_t N,
-                             unsigned short* d_index, int* d_argb, hipStream_t s) {
+                             unsigned short* d_index, int* d_argb, unsigned* d_todo /* [N + 1] */, hipStream_t s) {
     const FastArgs F = fast_args(P, lv, d_packed, s);
-    hipLaunchKernelGGL(fast_lookup_only_kernel, dim3(fast_grid(N)), dim3(256), 0, s, P, to_lists_fast(lv), F, d_palette, d_pixels, (long long) N,
-                       d_index, d_argb);
+    (void) hipMemsetAsync(d_todo, 0, sizeof(unsigned), s);
+    int64_t g1 = (N + 255) / 256;
+    if (g1 > 256 * 32) g1 = 256 * 32;                // 32 workgroups per CU in flight: 8 wavefronts per SIMD, four passes over them
+    if (g1 < 1) g1 = 1;
+    hipLaunchKernelGGL(fast_lookup_pass1_kernel, dim3((unsigned) g1), dim3(256), 0, s, P, F, d_palette, d_pixels, (long long) N, d_index, d_argb, d_todo);
+    hipLaunchKernelGGL(fast_lookup_pass2_kernel, dim3(1024), dim3(256), 0, s, P, to_lists_fast(lv), F, d_palette, d_pixels, d_index, d_argb,
+                       (const unsigned*) d_todo);
 }
 void launch_fast_bluenoise(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_pixels, int width, int height,
                            int y_origin, float weight, long long seed, unsigned short* d_index, int* d_argb, hipStream_t s) {

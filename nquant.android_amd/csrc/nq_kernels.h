@@ -88,8 +88,9 @@ void launch_fast_nearest_index(const DevParams& P, const ListsView& lv, const in
                                short* d_out, hipStream_t s);
 void launch_fast_closest_tuple(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_colors, int64_t M,
                                int* d_out4, hipStream_t s);
+// d_todo: unsigned[N + 1] scratch (the pixels the float32 pass leaves to the exact pass)
 void launch_fast_lookup_only(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_pixels, int64_t N,
-                             unsigned short* d_index, int* d_argb, hipStream_t s);
+                             unsigned short* d_index, int* d_argb, unsigned* d_todo, hipStream_t s);
 void launch_fast_bluenoise(const DevParams& P, const ListsView& lv, const int* d_palette, void* d_packed, const int* d_pixels, int width, int height,
                            int y_origin, float weight, long long seed, unsigned short* d_index, int* d_argb, hipStream_t s);
 // BlueNoise.dither post-pass (NQ/BlueNoise.java:207-222); in-place on d_index, writes d_argb

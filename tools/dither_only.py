@@ -1,5 +1,5 @@
 """Runs the dither pass of the bench image `reps` times (for rocprofv3 --kernel-trace --stats / --pmc).
-Usage: python tools/dither_only.py [size] [reps] [tile] [fast 0|1] [dither 0|1]"""
+Usage: python tools/dither_only.py [size] [reps] [tile] [fast 0|1] [dither 0|1] [mode 1 = PARALLEL_TILED | 2 = LOOKUP_ONLY]"""
 import os
 import sys
 
@@ -14,6 +14,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 tile = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 fast = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dither = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+mode = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 img = synth.gradient_noise(W, H, 3)
 d_in = torch.from_numpy(img.reshape(-1)).cuda()
 q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), mode=1, seed=3)
@@ -24,6 +25,6 @@ q.set_option(host.OPT_FAST_DITHER, fast)
 d_out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
 d_idx = torch.zeros(W * H, dtype=torch.int16, device="cuda")
 for it in range(reps):
-    q.dither_device(d_in.data_ptr(), pal, bool(dither), d_out.data_ptr(), d_idx.data_ptr())
+    q.dither_device(d_in.data_ptr(), pal, bool(dither), d_out.data_ptr(), d_idx.data_ptr(), mode=mode)
 torch.cuda.synchronize()
 print("done", q.dither_path())
