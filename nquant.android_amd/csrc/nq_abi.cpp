@@ -581,7 +581,14 @@ int pnnquan_prepare(nq_handle* h, const uint32_t* d_argb, int width, int height,
     if (n > 2147483647LL) NQ_FAIL(h, NQ_ERR_INVALID, "image larger than a Java int[]");
     long long* d_scan3 = h->d_scalars.p + 1;
     rec(h, 0);
-    launch_prescan((const int*) d_argb, n, 0, d_scan3, h->stream);
+    // the common case (nMaxColors >= 64: 5-6-5 keys unless the scan finds transparency) gets the sort words with the scan's read
+    bool words = false;
+    if (nMaxColors >= 64) {
+        int rcw = reserve_palette_ws(h, n);
+        if (rcw) return rcw;
+        words = launch_front((const int*) d_argb, n, d_scan3, h->sc->vals_a.p, (int) 0x00FFFFFFu, h->stream);
+    }
+    if (!words) launch_prescan((const int*) d_argb, n, 0, d_scan3, h->stream);
     long long scan3[3];
     NQ_HIP(h, hipMemcpyAsync(scan3, d_scan3, sizeof scan3, hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -605,7 +612,9 @@ int pnnquan_prepare(nq_handle* h, const uint32_t* d_argb, int width, int height,
     nq::SortWorkspace ws;
     ws.keys_a = h->sc->keys_a.p; ws.keys_b = h->sc->keys_b.p; ws.vals_a = h->sc->vals_a.p; ws.vals_b = h->sc->vals_b.p;
     ws.tmp = h->sc->sort_tmp.p; ws.tmp_bytes = h->sc->sort_tmp.n; ws.seg_start = h->sc->seg.p; ws.seg_end = h->sc->seg.p + 65536;
-    launch_histogram(h->kind, (const int*) d_argb, n, hp, ws, h->sc->hist.p, h->stream);
+    // (the speculative words hold 5-6-5 keys and the default transparent colour: right exactly for an image without transparency)
+    const bool words_ready = words && !hp.hasSemi && !hp.hasTransp;
+    launch_histogram(h->kind, (const int*) d_argb, n, hp, ws, h->sc->hist.p, h->stream, words_ready);
     return palette_prepare(h, h->sc->hist.p, 1, nMaxColors, out_palette, out_K, d_argb, n, job);
 }
 

@@ -132,8 +132,13 @@ void launch_color_presence(const int* d_pixels, int64_t n, int transparentColor,
                            unsigned* d_counters, hipStream_t s);
 void launch_ciede_selftest(const float* d_pairs /* n x 6 */, int64_t n, unsigned* d_out /* n x 9 */, hipStream_t s);
 void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s);
+// pre-scan + the histogram's packed sort words (5-6-5 keys, default transparent colour) in one read of the image; false: not
+// applicable (n not a multiple of 4 / unaligned buffers) and nothing was launched.  The words are valid only if the scan then
+// reports no alpha == 0 pixel and no semi-transparency and nMaxColors >= 64 (launch_histogram(..., words_ready = true)).
+bool launch_front(const int* d_pixels, int64_t n, long long* d_scan3, int* d_words /* SortWorkspace::vals_a */, int defaultTransparent,
+                  hipStream_t s);
 void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams& hp, const SortWorkspace& ws,
-                      double* d_hist, hipStream_t s);
+                      double* d_hist, hipStream_t s, bool words_ready = false);
 // d_blockcnt: int[64] scratch (occupied bins per 1024-bin slice)
 void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, int* d_blockcnt, hipStream_t s);
 void launch_quanfn(float* d_cnt, int maxbins, int fn, hipStream_t s);

@@ -188,11 +188,21 @@ void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long l
                        (long long) index_offset, d_scan3);
     hipLaunchKernelGGL(prescan_color_kernel, dim3(1), dim3(1), 0, s, d_pixels, (long long) n, (long long) index_offset, d_scan3);
 }
+bool launch_front(const int* d_pixels, int64_t n, long long* d_scan3, int* d_words, int defaultTransparent, hipStream_t s) {
+    if (n < 4 || (n & 3) || ((uintptr_t) d_pixels & 15) || ((uintptr_t) d_words & 15)) return false;
+    (void) hipMemsetAsync(d_scan3, 0xFF, 2 * sizeof(long long), s);      // {-1, -1}
+    (void) hipMemsetAsync(d_scan3 + 2, 0, sizeof(long long), s);
+    hipLaunchKernelGGL(front_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, s, (const int4*) d_pixels, (long long) (n / 4), 0LL,
+                       d_scan3, (uint4*) d_words, defaultTransparent);
+    hipLaunchKernelGGL(prescan_color_kernel, dim3(1), dim3(1), 0, s, d_pixels, (long long) n, 0LL, d_scan3);
+    return true;
+}
 void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams& hp, const SortWorkspace& ws,
-                      double* d_hist, hipStream_t s) {
+                      double* d_hist, hipStream_t s, bool words_ready) {
     unsigned* const pk_a = reinterpret_cast<unsigned*>(ws.vals_a);
     unsigned* const pk_b = reinterpret_cast<unsigned*>(ws.vals_b);
-    hipLaunchKernelGGL(bin_keys_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, hp, pk_a);
+    if (!words_ready)
+        hipLaunchKernelGGL(bin_keys_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, hp, pk_a);
     size_t tmp = ws.tmp_bytes;
     (void) rocprim::radix_sort_keys<HistSortConfig>(ws.tmp, tmp, (const unsigned*) pk_a, pk_b, (size_t) n, 16, 32, s);
     unsigned* const occ_count = ws.seg_end + 65536;             // (seg_start, seg_end, the counter: one contiguous clear)
