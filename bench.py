@@ -69,13 +69,16 @@ def cpu_baseline(workload, sample):
             "nproc": os.cpu_count()}
 
 
-def measured_traffic(w, h):
+LOOKUP_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "lookup_traffic.json")
+
+
+def measured_traffic(w, h, path=None):
     """HBM bytes per gilbert_kernel launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
     `bench.py --steps 1 --concurrency 1`, summaries under profiles/): 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
     MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests as 64 B; confirmed here on prescan_kernel: 32 787 KB for a 64 MiB read).
     Only valid for the image size it was measured on."""
     try:
-        t = json.load(open(TRAFFIC_FILE))
+        t = json.load(open(path or TRAFFIC_FILE))
         if t.get("width") == w and t.get("height") == h:
             return int(2 * t["FETCH_SIZE_KB"] * 1024 + t["WRITE_SIZE_KB"] * 1024)
     except Exception:
@@ -333,7 +336,8 @@ def main():
             la = LOOKUP_BYTES * npx / (lookup_ms * 1e-3) / 1e9
             line["roofline_lookup"] = {"bound": "hbm", "kernel": "fast_lookup_only_kernel (MODE_LOOKUP_ONLY: per-pixel nearestColorIndex, csrc/nq_dither_fast.hip)",
                                        "achieved": round(la, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(la / HBM_PEAK_GBPS, 5),
-                                       "traffic": None, "algorithmic_bytes_per_launch": LOOKUP_BYTES * npx, "kernel_ms": round(lookup_ms, 4),
+                                       "traffic": measured_traffic(W, H, LOOKUP_TRAFFIC_FILE), "algorithmic_bytes_per_launch": LOOKUP_BYTES * npx,
+                                       "kernel_ms": round(lookup_ms, 4),
                                        "mpixels_s": round(npx / (lookup_ms * 1e-3) / 1e6, 1)}
         whole_ms = dt / images * 1e3 * world        # time one rank spends per image, all stages
         line["roofline_whole"] = {"bound": "hbm", "what": "8 B/pixel over the whole convert() of one image (all stages, batch amortised)",

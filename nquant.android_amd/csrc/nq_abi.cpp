@@ -279,7 +279,7 @@ int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
     // (a negative ratio makes the closest error non-monotone in its terms: the list argument does not hold, full scans)
     if (!(h->kind == NQ_KIND_LAB && P.ratio < 0)) { out->closest = base; out->closestCount = base + 2 * LB; }
     if (nearest) { out->nearest = base + LB; out->nearestCount = base + 2 * LB + 65536; }
-    if (h->use_fast_dither && fast_lookup_eligible(P, *out)) launch_pack_lists(*out, packed_lists(h), h->stream);
+    if (h->use_fast_dither && fast_pack_wanted(P, *out)) launch_pack_lists(*out, packed_lists(h), h->stream);
     return NQ_OK;
 }
 

@@ -334,6 +334,32 @@ __device__ __forceinline__ int fast_nearest(const FastLds& S, const FastLookup& 
     return k1;
 }
 
+// RGB nearestColorIndex (NQ/PnnQuantizer.java:276-310) of an OPAQUE colour over the listed candidates of its cell: the reference's own f64
+// statement sequence in index order (four multiply-adds per candidate: no float32 filter needed), ties to the higher index.
+__device__ __forceinline__ int fast_nearest_rgb(const FastLds& S, double pa, double pr, double pg, double pb, int c, uint4 na, int n2,
+                                                const uint4* cont_cell) {
+    const int cr = c_red(c), cg = c_green(c), cb = c_blue(c);
+    double mindist = 2147483647.0;
+    int k = 0;
+    unsigned w0 = na.x, w1 = na.y, w2 = na.z, w3 = na.w;
+#pragma unroll 1
+    for (int t = 0; t < n2; ++t) {
+        if (t == 15) { const uint4 m = *cont_cell; w0 = m.x; w1 = m.y; w2 = m.z; w3 = m.w; }
+        const int i = (int) (w0 & 0xFF);
+        w0 = __builtin_amdgcn_alignbyte(w1, w0, 1); w1 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+        w2 = __builtin_amdgcn_alignbyte(w3, w2, 1); w3 >>= 8;
+        const int c2 = S.argb[i];
+        double curdist = pa * sqr((double) (c_alpha(c2) - 255));
+        curdist += pr * sqr((double) (c_red(c2) - cr));
+        curdist += pg * sqr((double) (c_green(c2) - cg));
+        curdist += pb * sqr((double) (c_blue(c2) - cb));
+        if (curdist > mindist) continue;          // (the partial-sum gates of the reference only skip what this one skips)
+        mindist = curdist;
+        k = i;
+    }
+    return k;
+}
+
 // which of the two closest candidates (NQ/PnnLABQuantizer.java:465-468): 0 when closest[2] == 0 or
 // random.nextInt(32767) % (closest[3] + closest[2]) <= closest[3], else 1; draws from `rng` exactly when the reference does
 __device__ __forceinline__ int fast_closest_pick(const FastClosest& t, long long& rng) {
@@ -431,7 +457,10 @@ __device__ __forceinline__ void fast_accumulate(const float (&q)[NQ_FQ][4], floa
     asm volatile("; window offset %0" :: "n"(U));
 }
 
-template <int MINWAVES>
+// KIND 1: PnnLABQuantizer (the family described at the top).  KIND 0: PnnQuantizer with dither = true, 32 < K <= 256, an image without
+// transparency: GilbertCurve has no saliencies there, so a step is accumulate -> nearestColorIndex(c2) -> limiter -> queue
+// (NQ/GilbertCurve.java:212-229 takes the plain lookup; NQ/PnnQuantizer.java:377-391 getDitherFn(true) = nearestColorIndex).
+template <int MINWAVES, int KIND = 1>
 __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P, GilbertConsts G, TileGeom T, CellLists lists, FastArgs F,
                                                                       const int* __restrict__ pixels, const float* __restrict__ saliency,
                                                                       const int* __restrict__ g_palette, long long seed,
@@ -456,8 +485,10 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
         int* a = (int*) S.argb; float4* l = (float4*) S.lab; double* g = (double*) S.gamma; float* g32 = (float*) S.gamma32;
         int c2 = tid < K ? g_palette[tid] : 0;
         a[tid] = c2;
-        const Lab l2 = RGB2LAB(c2);                    // getLab(palette[i]) (NQ/PnnLABQuantizer.java:352)
-        l[tid] = make_float4(l2.L, l2.A, l2.B, 0.f);
+        if (KIND == 1) {
+            const Lab l2 = RGB2LAB(c2);                // getLab(palette[i]) (NQ/PnnLABQuantizer.java:352)
+            l[tid] = make_float4(l2.L, l2.A, l2.B, 0.f);
+        }
         g[tid] = g_tab.gamma[tid];
         g32[tid] = (float) g_tab.gamma[tid];
         for (int i = tid; i < 1024; i += 256) ((int*) S.blue)[i] = ((const int*) g_tab.blue)[i];
@@ -481,8 +512,10 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
     const int width = T.width;
     long long rng = jr_seed((long long) mix64((unsigned long long) seed + (unsigned long long) (T.tile_base + tile)));
     const int gofs = T.y_origin * width;        // band-local pixel index -> pixel index in the whole image (TileGeom::y_origin)
-    const bool branchA = G.hasSaliencies && G.dither;                      // (!hasAlphaW: no semi-transparency here)
-    const bool hasSal = G.hasSaliencies != 0;
+    const bool branchA = KIND == 1 && G.hasSaliencies && G.dither;         // (!hasAlphaW: no semi-transparency here)
+    const bool hasSal = KIND == 1 && G.hasSaliencies != 0;
+    // RGB nearestColorIndex weights (NQ/PnnQuantizer.java:281-285; K > 2 here)
+    const double rpa = P.PA, rpr = P.PR, rpg = P.PG, rpb = P.PB;
     FastLookup X;
     X.packed = F.packed; X.cont = F.cont; X.qa = F.qa; X.qb = F.qb; X.qc = F.qc;
     X.ratio = P.ratio; X.wr = P.PR * (1 - P.ratio); X.wg = P.PG * (1 - P.ratio); X.wb = P.PB * (1 - P.ratio);
@@ -543,7 +576,18 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
 
             // ---- Ditherable.nearestColorIndex(palette, c, bidx) = closestColorIndex (K > 4), NQ/PnnLABQuantizer.java:407-474
             int qidx = 0;
-            if (c_alpha(c) <= 0xF) failed = true;           // transparent colour: the generic kernel redoes this tile
+            if (KIND == 0) {
+                // the candidate lists hold for opaque colours only (the alpha term of an entry is then the same for the whole cell)
+                if (c_alpha(c) != 255) failed = true;
+                else {
+                    const int cell = cell_of(c);
+                    const uint4 na = X.packed[2 * cell + 1];
+                    const int nnr = (int) (na.w >> 24);
+                    if (nnr == 255) failed = true;
+                    else qidx = fast_nearest_rgb(S, rpa, rpr, rpg, rpb, c, na, nnr, X.cont + 65536 + cell);
+                }
+            }
+            else if (c_alpha(c) <= 0xF) failed = true;      // transparent colour: the generic kernel redoes this tile
             else {
                 const int cell = NQ_KO(1) ? 0 : cell_of(c);
                 const uint4 la = X.packed[2 * cell], na = X.packed[2 * cell + 1];
@@ -851,9 +895,16 @@ static inline CellLists to_lists_fast(const ListsView& v) {
 // then runs the generic kernel over that list.
 bool gilbert_fast_eligible(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv) {
     const int tilepx = T.tile_w * T.tile_h;
-    return P.kind == 1 && P.K > 32 && P.K <= 256 && !P.hasSemi && !P.rewriteA0 && !G.sortedByYDiff && !G.hasAlphaW && G.DITHER_MAX == 25 &&
-           fast_weights_match(G.weights) && lv.closest && lv.nearest && P.ratio >= 0 && tilepx >= 1 && tilepx <= 1024 &&
-           fast_lds_bytes(tilepx, fast_stride_bytes(tilepx)) <= 160 * 1024 - 512;
+    const bool common = P.K > 32 && P.K <= 256 && !P.hasSemi && !P.rewriteA0 && !G.sortedByYDiff && !G.hasAlphaW && G.DITHER_MAX == 25 &&
+                        fast_weights_match(G.weights) && lv.nearest && tilepx >= 1 && tilepx <= 1024 &&
+                        fast_lds_bytes(tilepx, fast_stride_bytes(tilepx)) <= 160 * 1024 - 512;
+    if (P.kind == 1) return common && lv.closest && P.ratio >= 0;
+    // PnnQuantizer: dither = true (nearestColorIndex), no transparent colour (the RGB nearest lists exist for such images only), no saliencies
+    return common && G.dither && !P.hasAlpha && !G.hasSaliencies;
+}
+// the packed records are needed by the LAB lookups and by the RGB dither kernel
+bool fast_pack_wanted(const DevParams& P, const ListsView& lv) {
+    return fast_lookup_eligible(P, lv) || (P.kind == 0 && P.K > 32 && P.K <= 256 && !P.hasSemi && !P.hasAlpha && lv.nearest && lv.closest);
 }
 // the packed list records every specialised kernel reads (the ABI calls this right behind the list builders, in front of the stage
 // event of the per-pixel pass)
@@ -896,11 +947,20 @@ hipError_t launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const
     if (lds > 64 * 1024) {
         // more than 64 KB of dynamic LDS (16x16 tiles) needs the opt-in.  The attribute belongs to the function ON THE CURRENT DEVICE, so it
         // is set at every such launch (a host-side call, no process-wide flag: handles of several devices and threads stay independent)
-        e = hipFuncSetAttribute((const void*) gilbert_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        e = hipFuncSetAttribute((const void*) gilbert_fast_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((gilbert_fast_kernel<2>), dim3(grid), dim3(256), lds, s, P, G, T, to_lists_fast(lv), F, d_pixels, d_saliency, d_palette,
-                       seed, d_index, d_argb);
+    if (P.kind == 1)
+        hipLaunchKernelGGL((gilbert_fast_kernel<2, 1>), dim3(grid), dim3(256), lds, s, P, G, T, to_lists_fast(lv), F, d_pixels, d_saliency, d_palette,
+                           seed, d_index, d_argb);
+    else {
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute((const void*) gilbert_fast_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((gilbert_fast_kernel<2, 0>), dim3(grid), dim3(256), lds, s, P, G, T, to_lists_fast(lv), F, d_pixels, d_saliency, d_palette,
+                           seed, d_index, d_argb);
+    }
     return hipGetLastError();
 }
 

@@ -75,12 +75,14 @@ void launch_gilbert(const DevParams& P, const GilbertConsts& G, const TileGeom& 
                     int* d_log, int* d_log_count, unsigned char* d_seen, int log_cap,
                     // nullable: {count, tile indices...} -- walk only these tiles (the ones gilbert_fast_kernel handed back)
                     const int* d_tile_list, hipStream_t s);
-// nq_dither_fast.hip: the specialised kernel for LAB, 32 < K <= 256, no semi-transparency, DITHER_MAX 25, tiled
+// nq_dither_fast.hip: the specialised kernel for 32 < K <= 256, no semi-transparency, DITHER_MAX 25, tiled: PnnLABQuantizer, and
+// PnnQuantizer with dither = true on images without transparency
 bool gilbert_fast_eligible(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv);
 hipError_t launch_gilbert_fast(const DevParams& P, const GilbertConsts& G, const TileGeom& T, const ListsView& lv, const int* d_pixels,
                                const float* d_saliency, const int* d_palette, long long seed, unsigned short* d_index, int* d_argb,
                                int* d_failed /* int[1 + tiles] */, void* d_packed /* 65536 x 64 bytes */, hipStream_t s);
 bool fast_lookup_eligible(const DevParams& P, const ListsView& lv);
+bool fast_pack_wanted(const DevParams& P, const ListsView& lv);     // the packed records are needed (LAB lookups, or the RGB dither kernel)
 // packs the two lists of every colour cell into the 32-byte records (+ continuations) the specialised kernels read; must follow
 // launch_build_lists on the same stream whenever fast_lookup_eligible() holds
 void launch_pack_lists(const ListsView& lv, void* d_packed, hipStream_t s);

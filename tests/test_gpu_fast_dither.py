@@ -216,3 +216,51 @@ def test_bench_image_4096_rows_vs_oracle_and_whole_image_vs_generic(nq, oracle):
         ys = slice(r * 8, r * 8 + 8)
         assert (outs[1][1][ys].astype(np.int32) == want_idx[ys]).all(), "tile row %d differs from the oracle" % r
         assert (outs[1][0][ys] == want_argb[ys]).all()
+
+
+# ---- PnnQuantizer (RGB kind) through the specialised kernel ---------------------------------------------------------------------
+def _almost_opaque(img, seed, p=0.03):
+    """a few pixels with alpha 0xF0 (>= 0xE0: neither transparent nor semi-transparent for the pre-scan): the accumulated alpha leaves 255
+    around them, the opaque-colour candidate lists do not apply there and those tiles must be handed back to the generic kernel"""
+    z = synth.splitmix64(seed ^ 0xA1FA, img.size).reshape(img.shape)
+    out = img.view(np.uint32).copy()
+    sel = (z % np.uint64(10000)) < np.uint64(int(p * 10000))
+    out[sel] = (out[sel] & np.uint32(0x00FFFFFF)) | np.uint32(0xF0000000)
+    return out.view(np.int32)
+
+
+RGB_FAST_CASES = [  # K, image, tile (None = automatic), expect tiles handed back
+    (256, lambda: synth.uniform_rgb(192, 160, 137), (8, 8), False),                     # ~24 000 bins: DITHER_MAX 25 by itself
+    (100, lambda: synth.gradient_noise(320, 240, 302, noise=40), (4, 4), False),
+    (64, lambda: synth.gradient_noise(200, 150, 511, noise=40), (8, 8), False),
+    (128, lambda: synth.gradient_noise(398, 299, 303, noise=48), None, False),          # ragged automatic tiles
+    (256, lambda: _almost_opaque(synth.uniform_rgb(192, 160, 512), 512), (8, 8), True),
+]
+
+
+@pytest.mark.parametrize("K,mk,tile,handed", RGB_FAST_CASES)
+def test_rgb_kind_through_the_specialised_kernel(nq, oracle, K, mk, tile, handed):
+    """PnnQuantizer.convert(K, dither = true) on images without transparency: the RGB instantiation of the specialised dither kernel
+    (accumulate -> nearestColorIndex over the cell's candidate list -> limiter) == the oracle's tiled restatement == the generic kernel."""
+    img = mk()
+    seed = 77
+    h, w = img.shape
+    otile = tile if tile is not None else auto_tile(w, h)
+    oq, pal = _oracle_palette(oracle, 0, img, K)
+    op = oq.params
+    params = _copy_params(op, nq.Params)
+    expect_fast = 32 < len(pal) <= 256 and not op.hasSemiTransparency and op.transparentPixelIndex < 0 and 0.0025 < op.weight < 0.015
+    oq.set_seed(seed)
+    want_argb, want_idx = oq.dither(pal, True, tile=otile)
+    for fast in (1, 0):
+        gq = nq.PnnQuantizer(img, mode=TILED, seed=seed, tile=tile)
+        gq.set_params(params)
+        gq.set_option(OPT_FAST, fast)
+        got_argb, got_idx = gq.dither(pal, True)
+        ran_fast, handed_back = gq.dither_path()
+        assert ran_fast == (1 if (fast and expect_fast) else 0), (fast, ran_fast, op.weight, len(pal))
+        if fast and expect_fast:
+            assert (handed_back > 0) == handed, handed_back
+        bad = (got_idx.astype(np.int32) != want_idx).sum()
+        assert bad == 0, "fast=%d: index mismatches %d of %d (tiles handed back: %d)" % (fast, bad, want_idx.size, handed_back)
+        assert (got_argb != want_argb).sum() == 0
