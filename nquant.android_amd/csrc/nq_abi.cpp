@@ -523,18 +523,20 @@ int merge_launch(nq_handle* owner, const PaletteJob* const* jobs, int n) {
         if (pass == 1) n_lab = (int) host.size();
     }
     if (host.empty()) return NQ_OK;
-    // merge teams: when the LAB loops of this call leave CUs free (one 512-thread workgroup per CU), every loop gets helper workgroups
-    // that evaluate find_nn speculatively (nq_merge.inc); their hand-off words start zeroed
-    const int helpers = nq::merge_team_helpers(n_lab, (int) host.size());
-    for (int i = 0; i < n_lab; ++i) {
-        host[i].helpers = helpers;
-        if (helpers > 0) NQ_HIP(owner, hipMemsetAsync(host[i].team, 0, 256 * sizeof(unsigned long long), owner->stream));
+    // merge teams: when the loops of one kind in this call leave CUs free (one 512-thread workgroup per CU), every loop gets helper
+    // workgroups that evaluate find_nn speculatively (nq_merge.inc); their hand-off words start zeroed.  The two kinds run one after
+    // the other on this stream, so each is sized on its own.
+    const int n_rgb = (int) host.size() - n_lab;
+    const int helpers_lab = nq::merge_team_helpers(n_lab, (int) host.size()), helpers_rgb = nq::merge_team_helpers(n_rgb, (int) host.size());
+    for (int i = 0; i < (int) host.size(); ++i) {
+        host[i].helpers = i < n_lab ? helpers_lab : helpers_rgb;
+        if (host[i].helpers > 0) NQ_HIP(owner, hipMemsetAsync(host[i].team, 0, 256 * sizeof(unsigned long long), owner->stream));
     }
     NQ_HIP(owner, owner->d_jobs.reserve(host.size()));
     NQ_HIP(owner, hipMemcpyAsync(owner->d_jobs.p, host.data(), host.size() * sizeof(nq::MergeJob), hipMemcpyHostToDevice, owner->stream));
     NQ_HIP(owner, hipStreamSynchronize(owner->stream));    // `host` goes out of scope
-    launch_merge(1, owner->d_jobs.p, n_lab, (int) host.size(), helpers, owner->stream);
-    launch_merge(0, owner->d_jobs.p + n_lab, (int) host.size() - n_lab, (int) host.size(), 0, owner->stream);
+    launch_merge(1, owner->d_jobs.p, n_lab, (int) host.size(), helpers_lab, owner->stream);
+    launch_merge(0, owner->d_jobs.p + n_lab, n_rgb, (int) host.size(), helpers_rgb, owner->stream);
     NQ_HIP(owner, hipGetLastError());
     return NQ_OK;
 }

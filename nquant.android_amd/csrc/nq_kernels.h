@@ -166,6 +166,6 @@ struct MergeJob {
 // same number): the grid holds 1 + helpers workgroups per job (merge teams, nq_merge.inc).
 void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int helpers, hipStream_t s);
 // helpers launch_merge would use for n LAB jobs that are alone on the device (0..7; NQ_MERGE_HELPERS overrides)
-int merge_team_helpers(int n_lab_jobs, int n_in_flight);
+int merge_team_helpers(int n_jobs, int n_in_flight);
 
 } // namespace nq

@@ -260,9 +260,9 @@ static int merge_threads_for(int n_in_flight) {
     }
     return n_in_flight <= 256 ? 512 : n_in_flight <= 512 ? 256 : 128;
 }
-int merge_team_helpers(int n_lab_jobs, int n_in_flight) {
-    if (n_lab_jobs <= 0 || merge_threads_for(n_in_flight) != 512) return 0;
-    const int n_pad = (n_lab_jobs + 7) / 8 * 8;
+int merge_team_helpers(int n_jobs, int n_in_flight) {
+    if (n_jobs <= 0 || merge_threads_for(n_in_flight) != 512) return 0;
+    const int n_pad = (n_jobs + 7) / 8 * 8;
     int h = 256 / n_pad - 1;                       // one 512-thread workgroup per CU, 256 CUs
     if (h > 7) h = 7;
     if (h < 0) h = 0;
@@ -276,9 +276,10 @@ void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int 
     if (n <= 0) return;
     const int threads = merge_threads_for(n_in_flight);
     if (threads == 512) {
-        if (kind == 1 && helpers > 0) {
+        if (helpers > 0) {
             const int n_pad = (n + 7) / 8 * 8;
-            launch_merge_variant(m512::merge_kernel<1, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
+            if (kind == 1) launch_merge_variant(m512::merge_kernel<1, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
+            else launch_merge_variant(m512::merge_kernel<0, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
         }
         else if (kind == 1) launch_merge_variant(m512::merge_kernel<1>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
         else launch_merge_variant(m512::merge_kernel<0>, sizeof(m512::MergeLds), 512, d_jobs, n, s);

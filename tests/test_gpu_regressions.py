@@ -26,8 +26,9 @@ def test_rgb_pruned_scan_with_no_candidate_in_the_seed_blocks(nq, oracle, monkey
         assert len(got) == len(want) and (got == want).all()
 
 
-def test_merge_teams_with_helpers_that_never_become_resident(nq, oracle, monkeypatch):
-    """Merge teams (csrc/nq_merge.inc): 100 LAB merge loops with 3 helper workgroups each = 400 workgroups of 512 threads for 256 CUs, so the
+@pytest.mark.parametrize("kind", [1, 0])
+def test_merge_teams_with_helpers_that_never_become_resident(nq, oracle, monkeypatch, kind):
+    """Merge teams (csrc/nq_merge.inc): 100 merge loops (LAB, then RGB) with 3 helper workgroups each = 400 workgroups of 512 threads for 256 CUs, so the
     helpers of the third role and part of the second are not resident while their masters run.  The masters must notice (bounded waits,
     then they stop asking that helper), finish with the oracle's palettes, and the late helpers must leave on `done`."""
     import torch
@@ -38,7 +39,7 @@ def test_merge_teams_with_helpers_that_never_become_resident(nq, oracle, monkeyp
     imgs = [synth.gradient_noise(W, H, 700 + k) if k % 2 else synth.uniform_rgb(W, H, 700 + k) for k in range(n)]
     qs, ins, outs, idxs = [], [], [], []
     for k in range(n):
-        q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), mode=1, seed=5, tile=(8, 8))
+        q = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(np.zeros((1, 1), np.int32), mode=1, seed=5, tile=(8, 8))
         q.width, q.height = W, H
         qs.append(q); ins.append(torch.from_numpy(imgs[k].reshape(-1).copy()).cuda())
         outs.append(torch.zeros(W * H, dtype=torch.int32, device="cuda")); idxs.append(torch.zeros(W * H, dtype=torch.int16, device="cuda"))
@@ -48,7 +49,7 @@ def test_merge_teams_with_helpers_that_never_become_resident(nq, oracle, monkeyp
     assert all(q.team_stats()["helpers"] == 3 for q in qs)
     assert used > 0, "no helper result was used at all"
     for k in (0, 1, 37, 64, 98, 99):
-        oq = oracle.OracleQuantizer(1, imgs[k], seed=5)
+        oq = oracle.OracleQuantizer(kind, imgs[k], seed=5)
         oq.prescan(256)
         want = oq.pnnquan(256)
         assert len(pals[k]) == len(want) and (pals[k] == want).all(), "image %d" % k
