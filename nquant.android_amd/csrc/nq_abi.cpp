@@ -161,7 +161,7 @@ struct nq_handle {
     DevBuf<short> d_bincache, d_short;
     DevBuf<int> d_seqlog;             // REFERENCE_SEQUENTIAL + LAB + dither=false: colours getLab() saw during the pass (+ 1 counter)
     DevBuf<unsigned char> d_seqseen;  // ... and the palette entries it touched
-    DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..19] merge stats, [20..21] distinct-colour result
+    DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..19] merge stats, [20..21] distinct-colour result, [24..39] team counters, [40] palette status
     DevBuf<int> live3;                // merge loop: two live lists + position index
     int use_lists = 1;
     // nq_gilbert_dither / nq_bluenoise_dither: the static entry points of the reference run the same stages with caller-supplied
@@ -183,6 +183,7 @@ struct nq_handle {
     hipStream_t copy_stream = nullptr;
     hipStream_t lane_stream = nullptr;  // second lane of the batch entry points
     long long merge_stats[16] = {0};
+    long long merge_readback[37] = {0}; // d_scalars[4..41) as the merge kernel left it: one copy per image ([36] = status word)
     long long team_stats[16] = {0};    // merge teams: {work records published, results used, timed-out waits, ticks waited, helpers, still speculating}
     DevBuf<unsigned long long> team;  // 256 u64 of hand-off words of this handle's merge team
     hipEvent_t bev[4] = {nullptr};    // batch entry points: phase boundaries on the launch stream (first handle of the batch)
@@ -508,8 +509,8 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
     job->plen = extbins > 0 ? nMaxColors : maxbins;
     // the merge workgroup also fills the palette (P10)
     NQ_HIP(h, h->d_palette.reserve((size_t) std::max(job->plen, 2)));
-    NQ_HIP(h, hipMemsetAsync(h->d_ints.p + 1, 0, sizeof(int), h->stream));
-    job->mj.plen = job->plen; job->mj.palette = h->d_palette.p; job->mj.status = h->d_ints.p + 1;
+    NQ_HIP(h, hipMemsetAsync(h->d_scalars.p + 40, 0, sizeof(long long), h->stream));
+    job->mj.plen = job->plen; job->mj.palette = h->d_palette.p; job->mj.status = reinterpret_cast<int*>(h->d_scalars.p + 40);
     return NQ_OK;
 }
 
@@ -546,12 +547,14 @@ int merge_launch(nq_handle* owner, const PaletteJob* const* jobs, int n) {
 int palette_fetch(nq_handle* h, const PaletteJob& job, uint32_t* out_palette, int* status) {
     rec(h, 5);
     NQ_HIP(h, hipMemcpyAsync(out_palette, h->d_palette.p, job.plen * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    NQ_HIP(h, hipMemcpyAsync(status, h->d_ints.p + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    NQ_HIP(h, hipMemcpyAsync(h->merge_stats, h->d_scalars.p + 4, sizeof h->merge_stats, hipMemcpyDeviceToHost, h->stream));
-    NQ_HIP(h, hipMemcpyAsync(h->team_stats, h->d_scalars.p + 24, sizeof h->team_stats, hipMemcpyDeviceToHost, h->stream));
+    NQ_HIP(h, hipMemcpyAsync(h->merge_readback, h->d_scalars.p + 4, sizeof h->merge_readback, hipMemcpyDeviceToHost, h->stream));
+    (void) status;
     return NQ_OK;
 }
 int palette_check(nq_handle* h, const PaletteJob& job, int status, int32_t* out_K) {
+    std::memcpy(h->merge_stats, h->merge_readback, sizeof h->merge_stats);
+    std::memcpy(h->team_stats, h->merge_readback + 20, sizeof h->team_stats);
+    status = (int) (h->merge_readback[36] & 0xFFFFFFFFLL);
     if (h->merge_stats[14]) NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "merge loop stopped by its watchdog (more than maxbins^2/2 find_nn calls, 240 s of wall clock, or an empty heap)");
     if (status) NQ_FAIL(h, NQ_ERR_REFERENCE_THROWS, "ColorUtils.setAlphaComponent: alpha outside 0..255 (the reference throws IllegalArgumentException)");
     h->params.paletteLength = job.plen;

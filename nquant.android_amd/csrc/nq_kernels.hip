@@ -208,10 +208,9 @@ void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams
     unsigned* const occ_count = ws.seg_end + 65536;             // (seg_start, seg_end, the counter: one contiguous clear)
     unsigned* const occ_list = occ_count + 64;
     (void) hipMemsetAsync(ws.seg_start, 0, (2 * 65536 + 1) * sizeof(unsigned), s);
-    (void) hipMemsetAsync(d_hist, 0, (size_t) 65536 * 5 * sizeof(double), s);        // empty bins are not visited any more
     hipLaunchKernelGGL(seg_bounds_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, (const unsigned*) pk_b, (long long) n,
                        ws.seg_start, ws.seg_end);
-    hipLaunchKernelGGL(occupied_bins_kernel, dim3(64), dim3(1024), 0, s, (const unsigned*) ws.seg_start, (const unsigned*) ws.seg_end, occ_count, occ_list);
+    hipLaunchKernelGGL(occupied_bins_kernel, dim3(64), dim3(1024), 0, s, (const unsigned*) ws.seg_start, (const unsigned*) ws.seg_end, occ_count, occ_list, d_hist);
     const int keyfmt = hp.hasSemi ? 2 : hp.hasTransp ? 1 : 0;          // getColorIndex: 4-4-4-4 / 1-5-5-5 / 5-6-5
     if (kind == 1)
         hipLaunchKernelGGL(hist_segments_kernel<1>, dim3(65536 / 4), dim3(256), keyfmt == 2 ? 0 : (size_t) 4 * (keyfmt == 0 ? 256 : 512) * 16, s,
