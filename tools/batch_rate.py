@@ -1,6 +1,6 @@
 """Throughput of nq_convert_batch_device for either kind: python tools/batch_rate.py <batch> <kind 0|1> [side]"""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 import nquant.android_amd as nq
 from nquant.android_amd import synth

@@ -1,7 +1,7 @@
 """Single-convert latency and merge-loop counters on the bench image (4096^2 gradient+noise, LAB, 256 colours).
 python tools/latency.py [side] [kind 0|1] [uniform]"""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 import nquant.android_amd as nq
 from nquant.android_amd import synth
