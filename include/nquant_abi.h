@@ -241,12 +241,13 @@ int nq_get_stage_ms(const nq_handle* h, float* out8);
  * the bound pass, ticks in the exact pass, ticks in the replay, 64-candidate chunks visited, chunks that ran the level-1
  * bound, chunks that ran the tight bound, chunks that listed a candidate, aborted flag, ticks of the seed round inside the bound pass}. */
 int nq_get_merge_stats(const nq_handle* h, int64_t* out16);
-/* Counters of the last merge loop's TEAM (csrc/nq_merge.inc: a LAB merge loop that has the device to itself -- a single image, a batch
- * of up to 128 -- runs with up to three helper workgroups on other CUs that evaluate find_nn speculatively for the bins that will
- * surface next), 8 values: {work records published, helper results used in place of an own find_nn, waits for a result that timed
- * out, 100 MHz ticks spent waiting, helpers per loop, 1 if the loop was still speculating at its end, bin-info cache hits for the heap top,
- * ... for the merged neighbour, then the control thread's 100 MHz ticks in heap sifts / in merges / fetching the heap top's bin, the
- * deleted nodes popped, ticks in the find_nn epilogues, ticks wavefront 1 spent choosing work records, 0, 0}.  Diagnostics. */
+/* Counters of the last merge loop's TEAM (csrc/nq_merge.inc: a merge loop that has CUs to spare -- a single image, a batch of up to 128 -- runs as a master
+ * workgroup plus 1 - 7 helper workgroups that evaluate find_nn speculatively for the bins that will surface next), 16 values:
+ * {work records published, helper results used in place of an own find_nn, waits for a result that timed out, 100 MHz ticks spent
+ * waiting, helpers per loop, 1 if the loop was still speculating at its end, bin-info cache hits for the heap top, ... for the merged
+ * neighbour, then the control thread's 100 MHz ticks in heap sifts / in merges / fetching the heap top's bin, the deleted nodes
+ * popped, ticks in the find_nn epilogues, ticks spent choosing work records, results a helper declined (RGB), times the loop gave up
+ * on its helpers for a while}.  Diagnostics. */
 int nq_get_team_stats(const nq_handle* h, int64_t* out16);
 /* Phases of the last nq_convert_batch[_device] call, as seen by its FIRST handle: HIP-event spans on the launch stream, ms:
  * {every image's pre-scan + histogram + initial find_nn pass, the merge launch (all merge loops side by side + palette fill),

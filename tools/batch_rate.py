@@ -22,3 +22,11 @@ st = qs[0].merge_stats(); n = max(st["find_nn_calls"], 1)
 print("image 0 in the batch, per find us: find %.2f ctrl %.2f | bound %.2f (seed %.2f) exact %.2f replay %.2f | chunks %.1f exact evals %.2f overflows %d" % (
     st["find_ticks_100MHz"] / n / 100, st["ctrl_ticks_100MHz"] / n / 100, st["bound_ticks"] / n / 100, st["seed_round_ticks"] / n / 100,
     st["exact_ticks"] / n / 100, st["replay_ticks"] / n / 100, st["chunks"] / n, st["exact_evals"] / n, st["overflows"]))
+ts = qs[0].team_stats()
+print("image 0 team: helpers %d published %d used %d timeouts %d wait %.2f us per waited result, speculating at end %d" % (
+    ts["helpers"], ts["published"], ts["used"], ts["timeouts"], ts["wait_ticks_100MHz"] / max(ts["used"] + ts["timeouts"], 1) / 100, ts["speculating_at_end"]))
+tss = [q.team_stats() for q in qs]
+print("loops that gave up on their helpers at least once: %d of %d (%d times in all); without them at the end: %d" % (
+    sum(1 for t in tss if t["gave_up"]), B, sum(t["gave_up"] for t in tss), sum(1 for t in tss if t["helpers"] > 0 and not t["speculating_at_end"])))
+busy = sorted((q.merge_stats()["find_ticks_100MHz"] + q.merge_stats()["ctrl_ticks_100MHz"]) / 1e5 for q in qs)
+print("loop busy time (find + control) ms: min %.0f median %.0f p99 %.0f max %.0f | batch phases %s" % (busy[0], busy[len(busy) // 2], busy[int(len(busy) * 0.99)], busy[-1], qs[0].batch_phase_ms()))
