@@ -183,6 +183,8 @@ struct nq_handle {
     hipStream_t copy_stream = nullptr;
     hipStream_t lane_stream = nullptr;  // second lane of the batch entry points
     long long merge_stats[16] = {0};
+    std::vector<uint32_t> dev_palette;  // what d_palette holds, as far as the host knows (empty: unknown): an upload of the same entries is skipped
+    uint32_t* fetched_palette = nullptr; int fetched_len = 0;      // palette_fetch -> palette_check
     long long merge_readback[37] = {0}; // d_scalars[4..41) as the merge kernel left it: one copy per image ([36] = status word)
     long long team_stats[16] = {0};    // merge teams: {work records published, results used, timed-out waits, ticks waited, helpers, still speculating}
     DevBuf<unsigned long long> team;  // 256 u64 of hand-off words of this handle's merge team
@@ -247,6 +249,18 @@ DevParams dev_params(const nq_handle* h, int K) {
 }
 
 // the packed list records of the specialised kernels (nq_dither_fast.hip) live behind the lists and their counts
+// the palette of a per-pixel pass on the device; skipped when d_palette already holds exactly these entries (convert(): the merge
+// workgroup wrote them there and the host read them back -- one small copy per image less)
+int upload_palette(nq_handle* h, const uint32_t* palette, int K) {
+    const size_t cap = h->d_palette.n;
+    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(K, 2)));
+    if (h->d_palette.n != cap) h->dev_palette.clear();          // (a new allocation)
+    if ((int) h->dev_palette.size() == K && std::memcmp(h->dev_palette.data(), palette, (size_t) K * sizeof(uint32_t)) == 0) return NQ_OK;
+    h->dev_palette.clear();
+    NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    h->dev_palette.assign(palette, palette + K);
+    return NQ_OK;
+}
 void* packed_lists(nq_handle* h) { return h->sc->cell_lists.p + 2 * (size_t) 65536 * 32 + 2 * 65536; }
 
 // candidate lists per colour cell for this palette (nq_lists.inc); empty view = full scans
@@ -509,7 +523,7 @@ int palette_prepare(nq_handle* h, const double* d_hists, int n_bands, int nMaxCo
     job->plen = extbins > 0 ? nMaxColors : maxbins;
     // the merge workgroup also fills the palette (P10)
     NQ_HIP(h, h->d_palette.reserve((size_t) std::max(job->plen, 2)));
-    NQ_HIP(h, hipMemsetAsync(h->d_scalars.p + 40, 0, sizeof(long long), h->stream));
+    h->dev_palette.clear();                   // (the merge workgroup is about to write it)
     job->mj.plen = job->plen; job->mj.palette = h->d_palette.p; job->mj.status = reinterpret_cast<int*>(h->d_scalars.p + 40);
     return NQ_OK;
 }
@@ -547,6 +561,7 @@ int merge_launch(nq_handle* owner, const PaletteJob* const* jobs, int n) {
 int palette_fetch(nq_handle* h, const PaletteJob& job, uint32_t* out_palette, int* status) {
     rec(h, 5);
     NQ_HIP(h, hipMemcpyAsync(out_palette, h->d_palette.p, job.plen * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    h->fetched_palette = out_palette; h->fetched_len = job.plen;
     NQ_HIP(h, hipMemcpyAsync(h->merge_readback, h->d_scalars.p + 4, sizeof h->merge_readback, hipMemcpyDeviceToHost, h->stream));
     (void) status;
     return NQ_OK;
@@ -555,6 +570,8 @@ int palette_check(nq_handle* h, const PaletteJob& job, int status, int32_t* out_
     std::memcpy(h->merge_stats, h->merge_readback, sizeof h->merge_stats);
     std::memcpy(h->team_stats, h->merge_readback + 20, sizeof h->team_stats);
     status = (int) (h->merge_readback[36] & 0xFFFFFFFFLL);
+    if (h->fetched_palette) h->dev_palette.assign(h->fetched_palette, h->fetched_palette + h->fetched_len);
+    h->fetched_palette = nullptr;
     if (h->merge_stats[14]) NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "merge loop stopped by its watchdog (more than maxbins^2/2 find_nn calls, 240 s of wall clock, or an empty heap)");
     if (status) NQ_FAIL(h, NQ_ERR_REFERENCE_THROWS, "ColorUtils.setAlphaComponent: alpha outside 0..255 (the reference throws IllegalArgumentException)");
     h->params.paletteLength = job.plen;
@@ -647,8 +664,7 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     if (K > 8192) NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "palettes above 8192 entries do not fit the LDS staging");
     const int64_t n = (int64_t) width * height;
     nq_params& p = h->params;
-    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(K, 2)));
-    NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    { int rcp = upload_palette(h, palette, K); if (rcp) return rcp; }
     if (!d_out_index) { NQ_HIP(h, h->d_out_index.reserve((size_t) n)); d_out_index = h->d_out_index.p; }
     // stage events 5..7 belong to THIS call only once it has recorded all of them (set at the successful exits below); until then
     // nq_get_stage_ms reports what the last finished convert left
@@ -1298,8 +1314,8 @@ int nq_nearest_index(nq_handle* h, const uint32_t* palette, int K, const uint32_
     if (rc) return rc;
     if (!palette || K < 1 || K > 8192 || !colors || M < 0 || !out_index) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
     if (M == 0) return NQ_OK;
-    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(K, 2))); NQ_HIP(h, h->d_colors.reserve((size_t) M)); NQ_HIP(h, h->d_short.reserve((size_t) M));
-    NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    { int rcp = upload_palette(h, palette, K); if (rcp) return rcp; }
+    NQ_HIP(h, h->d_colors.reserve((size_t) M)); NQ_HIP(h, h->d_short.reserve((size_t) M));
     NQ_HIP(h, hipMemcpyAsync(h->d_colors.p, colors, (size_t) M * sizeof(int), hipMemcpyHostToDevice, h->stream));
     DevParams P = dev_params(h, K);
     nq::ListsView lv;
@@ -1321,8 +1337,8 @@ int nq_closest_tuple(nq_handle* h, const uint32_t* palette, int K, const uint32_
     if (rc) return rc;
     if (!palette || K < 1 || K > 8192 || !colors || M < 0 || !out_closest4) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
     if (M == 0) return NQ_OK;
-    NQ_HIP(h, h->d_palette.reserve((size_t) std::max(K, 2))); NQ_HIP(h, h->d_colors.reserve((size_t) M)); NQ_HIP(h, h->d_tuple.reserve((size_t) 4 * M));
-    NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    { int rcp = upload_palette(h, palette, K); if (rcp) return rcp; }
+    NQ_HIP(h, h->d_colors.reserve((size_t) M)); NQ_HIP(h, h->d_tuple.reserve((size_t) 4 * M));
     NQ_HIP(h, hipMemcpyAsync(h->d_colors.p, colors, (size_t) M * sizeof(int), hipMemcpyHostToDevice, h->stream));
     DevParams P = dev_params(h, K);
     nq::ListsView lv;

@@ -65,7 +65,8 @@ void launch_build_lists(const DevParams& P, const int* d_palette, double wA, dou
 }
 
 void launch_saliency(const DevParams& P, int salSubst, const int* d_pixels, int64_t N, float* d_out, hipStream_t s) {
-    hipLaunchKernelGGL(saliency_kernel, dim3(grid_for(N, 256, 256 * 16)), dim3(256), 0, s, P, salSubst, d_pixels, (long long) N, d_out);
+    const long long vec4 = (((uintptr_t) d_pixels | (uintptr_t) d_out) & 15) ? 0 : N / 4;
+    hipLaunchKernelGGL(saliency_kernel, dim3(grid_for(N / 4 + 1, 256, 256 * 8)), dim3(256), 0, s, P, salSubst, d_pixels, (long long) N, d_out, vec4);
 }
 
 void launch_nearest_index(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_colors, int64_t M, short* d_out, hipStream_t s) {
@@ -182,16 +183,14 @@ void launch_ciede_selftest(const float* d_pairs, int64_t n, unsigned* d_out, hip
     hipLaunchKernelGGL(ciede_selftest_kernel, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, d_pairs, (long long) n, d_out);
 }
 void launch_prescan(const int* d_pixels, int64_t n, int64_t index_offset, long long* d_scan3, hipStream_t s) {
-    (void) hipMemsetAsync(d_scan3, 0xFF, 2 * sizeof(long long), s);      // {-1, -1}
-    (void) hipMemsetAsync(d_scan3 + 2, 0, sizeof(long long), s);
+    (void) hipMemsetAsync(d_scan3, 0xFF, 3 * sizeof(long long), s);      // {-1, -1, -1}: prescan_color_kernel adds the 1 to the count
     hipLaunchKernelGGL(prescan_kernel, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, s, d_pixels, (long long) n,
                        (long long) index_offset, d_scan3);
     hipLaunchKernelGGL(prescan_color_kernel, dim3(1), dim3(1), 0, s, d_pixels, (long long) n, (long long) index_offset, d_scan3);
 }
 bool launch_front(const int* d_pixels, int64_t n, long long* d_scan3, int* d_words, int defaultTransparent, hipStream_t s) {
     if (n < 4 || (n & 3) || ((uintptr_t) d_pixels & 15) || ((uintptr_t) d_words & 15)) return false;
-    (void) hipMemsetAsync(d_scan3, 0xFF, 2 * sizeof(long long), s);      // {-1, -1}
-    (void) hipMemsetAsync(d_scan3 + 2, 0, sizeof(long long), s);
+    (void) hipMemsetAsync(d_scan3, 0xFF, 3 * sizeof(long long), s);      // {-1, -1, -1}: prescan_color_kernel adds the 1 to the count
     hipLaunchKernelGGL(front_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, s, (const int4*) d_pixels, (long long) (n / 4), 0LL,
                        d_scan3, (uint4*) d_words, defaultTransparent);
     hipLaunchKernelGGL(prescan_color_kernel, dim3(1), dim3(1), 0, s, d_pixels, (long long) n, 0LL, d_scan3);
@@ -205,12 +204,10 @@ void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams
         hipLaunchKernelGGL(bin_keys_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, hp, pk_a);
     size_t tmp = ws.tmp_bytes;
     (void) rocprim::radix_sort_keys<HistSortConfig>(ws.tmp, tmp, (const unsigned*) pk_a, pk_b, (size_t) n, 16, 32, s);
-    unsigned* const occ_count = ws.seg_end + 65536;             // (seg_start, seg_end, the counter: one contiguous clear)
+    unsigned* const occ_count = ws.seg_end + 65536;
     unsigned* const occ_list = occ_count + 64;
-    (void) hipMemsetAsync(ws.seg_start, 0, (2 * 65536 + 1) * sizeof(unsigned), s);
-    hipLaunchKernelGGL(seg_bounds_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, (const unsigned*) pk_b, (long long) n,
-                       ws.seg_start, ws.seg_end);
-    hipLaunchKernelGGL(occupied_bins_kernel, dim3(64), dim3(1024), 0, s, (const unsigned*) ws.seg_start, (const unsigned*) ws.seg_end, occ_count, occ_list, d_hist);
+    (void) hipMemsetAsync(occ_count, 0, sizeof(unsigned), s);
+    hipLaunchKernelGGL(occupied_bins_kernel, dim3(64), dim3(1024), 0, s, (const unsigned*) pk_b, (unsigned) n, ws.seg_start, ws.seg_end, occ_count, occ_list, d_hist);
     const int keyfmt = hp.hasSemi ? 2 : hp.hasTransp ? 1 : 0;          // getColorIndex: 4-4-4-4 / 1-5-5-5 / 5-6-5
     if (kind == 1)
         hipLaunchKernelGGL(hist_segments_kernel<1>, dim3(65536 / 4), dim3(256), keyfmt == 2 ? 0 : (size_t) 4 * (keyfmt == 0 ? 256 : 512) * 16, s,
