@@ -53,3 +53,34 @@ def test_merge_teams_with_helpers_that_never_become_resident(nq, oracle, monkeyp
         oq.prescan(256)
         want = oq.pnnquan(256)
         assert len(pals[k]) == len(want) and (pals[k] == want).all(), "image %d" % k
+
+
+def test_one_handle_many_palettes(nq):
+    """csrc/nq_abi.cpp upload_palette: an upload is skipped when `d_palette` already holds exactly the entries asked for (in convert() the
+    merge workgroup wrote them and the host read them back).  One handle must therefore keep giving, for every palette handed to
+    dither(), what a fresh handle gives: same length / different entries, the same entries again, a shorter and a longer palette, and a
+    convert() in between (which rewrites `d_palette` on the device)."""
+    img = synth.gradient_noise(96, 72, 91)
+    K = 48
+    ref = nq.PnnLABQuantizer(img, mode=nq.MODE_PARALLEL_TILED, seed=4, tile=(8, 8))
+    p1 = ref.pnnquan(K)
+    p2 = p1.copy(); p2[5:20] = p1[5:20] ^ 0x00101010          # same length, other colours
+    p3 = p1[:40].copy()
+    p4 = np.concatenate([p1, p2[5:20]])
+
+    params = ref.params
+
+    def fresh(p, dither):
+        q = nq.PnnLABQuantizer(img, mode=nq.MODE_PARALLEL_TILED, seed=4, tile=(8, 8))
+        q.set_params(params)
+        return q.dither(p, dither)[1]
+
+    one = nq.PnnLABQuantizer(img, mode=nq.MODE_PARALLEL_TILED, seed=4, tile=(8, 8))
+    one.set_params(params)
+    for p, dither in [(p1, True), (p2, True), (p2, True), (p1, False), (p3, True), (p4, True), (p1, True)]:
+        assert (one.dither(p, dither)[1] == fresh(p, dither)).all()
+    got = one.convert(K, True)                                # rewrites d_palette on the device
+    assert (got.palette == p1).all()
+    for p in (p2, p1):
+        one.set_params(params)
+        assert (one.dither(p, True)[1] == fresh(p, True)).all()
