@@ -189,6 +189,7 @@ struct nq_handle {
     long long merge_readback[37] = {0}; // d_scalars[4..41) as the merge kernel left it: one copy per image ([36] = status word)
     long long team_stats[16] = {0};    // merge teams: {work records published, results used, timed-out waits, ticks waited, helpers, still speculating}
     DevBuf<unsigned long long> team;  // 256 u64 of hand-off words of this handle's merge team
+    bool light_events = false;        // batch entry points: this image records only the stage events 0, 5, 6 (see rec)
     hipEvent_t bev[4] = {nullptr};    // batch entry points: phase boundaries on the launch stream (first handle of the batch)
     float batch_phase_ms[4] = {0};
     bool ext_distinct_valid = false, ext_distinct_many = false;  // nq_set_distinct: image-wide distinct colours (first-occurrence order) of the split pipeline
@@ -395,7 +396,13 @@ void apply_scan(nq_handle* h, int nMaxColors, int64_t transparent_index, uint32_
     p.distinctColors = 0;
 }
 
-void rec(nq_handle* h, int i) { (void) hipEventRecord(h->ev[i], h->stream); }
+// stage boundary i on the handle's stream.  An event record costs the GPU ~3 us of queue time, eight of them per image of a big batch
+// 0.9 % of the batch: the batch entry points keep all eight for their first images only, the rest record the start and the two ends of
+// the per-pixel pass (what bench.py's roofline needs)
+void rec(nq_handle* h, int i) {
+    if (h->light_events && ((i >= 1 && i <= 4) || i == 7)) return;
+    (void) hipEventRecord(h->ev[i], h->stream);
+}
 
 // what palette_prepare leaves for the merge launch and palette_finish; merge == false: the palette is already final
 struct PaletteJob {
@@ -840,11 +847,12 @@ void finish_timing(nq_handle* h) {
     // {prescan, histogram, nn_init, merge, palette_fill, dither, bluenoise, total}
     for (int i = 0; i < 7; ++i) {
         float ms = 0;
+        if (h->light_events && i != 5) { h->stage_ms[i] = 0; continue; }          // (not recorded: see rec)
         if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = 0;
         h->stage_ms[i] = ms;
     }
     float tot = 0;
-    if (hipEventElapsedTime(&tot, h->ev[0], h->ev[7]) != hipSuccess) tot = 0;
+    if (hipEventElapsedTime(&tot, h->ev[0], h->ev[h->light_events ? 6 : 7]) != hipSuccess) tot = 0;
     h->stage_ms[7] = tot;
     h->dither_events_fresh = false;
 }
@@ -1136,8 +1144,9 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
     // other lanes keep the GPU busy (NQ_BATCH_LANES = 1..4 overrides).  The merge launch joins the lanes.
     struct Restore {
         nq_handle* const* hs; int n; std::vector<hipStream_t> streams;
-        ~Restore() { for (int i = 0; i < n; ++i) { hs[i]->stream = streams[i]; hs[i]->sc = &hs[i]->own; } }
+        ~Restore() { for (int i = 0; i < n; ++i) { hs[i]->stream = streams[i]; hs[i]->sc = &hs[i]->own; hs[i]->light_events = false; } }
     } restore{hs, n, {}};
+    for (int i = 0; i < n; ++i) hs[i]->light_events = i >= 16;
     for (int i = 0; i < n; ++i) restore.streams.push_back(hs[i]->stream);
     auto fail_from = [&](nq_handle* h, int rc) { if (h != h0) h0->err = h->err; return rc; };
     for (int i = 0; i < n; ++i) {
