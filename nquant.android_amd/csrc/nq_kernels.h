@@ -162,10 +162,10 @@ struct MergeJob {
 };
 // d_jobs: n jobs of one kind in device memory, one workgroup per job.  n_in_flight = merge loops expected to run at the same
 // time on the device (the whole batch): <= 256 -> 512-thread workgroups, one per CU; <= 512 -> 256 threads, two per CU;
-// more -> 128 threads, four per CU.  helpers > 0 (LAB, 512-thread variant only; every job's `team` area zeroed and `helpers` set to the
-// same number): the grid holds 1 + helpers workgroups per job (merge teams, nq_merge.inc).
+// more -> 128 threads, four per CU.  helpers > 0 (either kind, 512-thread variant only; every job's `team` area zeroed and `helpers` set to
+// the same number): the grid holds 1 + helpers workgroups per job (merge teams, nq_merge.inc).
 void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int helpers, hipStream_t s);
-// helpers launch_merge would use for n LAB jobs that are alone on the device (0..7; NQ_MERGE_HELPERS overrides)
+// helpers launch_merge would use for n jobs of one kind when n_in_flight loops share the device (0..7; NQ_MERGE_HELPERS overrides)
 int merge_team_helpers(int n_jobs, int n_in_flight);
 
 } // namespace nq
