@@ -14,9 +14,15 @@ Prints ONE JSON line on rank 0 (contract in the round prompt) with extra objects
                     8 B/pixel (4 B ARGB read + 4 B ARGB write) / its average duration measured with HIP
                     events on the launch stream inside the timed region, against the 8 TB/s HBM peak;
   roofline_whole -- the same 8 B/pixel against the time of the WHOLE convert per image (all stages);
-  roofline_lookup -- fast_lookup_only_kernel (MODE_LOOKUP_ONLY: nearestColorIndex per pixel, the "dither off, bit-exact indices" half
-                    of the north star) on the same image and palette, measured after the timed region: 4 B read + 2 B index +
-                    4 B ARGB written = 10 B/pixel against its HIP-event time;
+  roofline_lookup -- fast_lookup_pass1_kernel + fast_lookup_pass2_kernel (MODE_LOOKUP_ONLY: nearestColorIndex per pixel, the "dither off,
+                    bit-exact indices" half of the north star) on the same image and palette, measured after the timed region: 4 B read +
+                    2 B index + 4 B ARGB written = 10 B/pixel against the HIP-event time of the two passes (the list of the pixels the
+                    float32 pass defers to the exact pass is not counted as algorithmic);
+  batch_sweep, cfg3a_uniform, photo, host_batch, single_image_mpixels_s -- N = 1 only, after the timed region (--no-extras skips them):
+                    smaller batches of the same images; BASELINE cfg 3 type (a) (uniform random colours, 65 536 bins: the worst case for
+                    pnnquan) as single-image latency and a batch of 256; the reference's own sample photograph tiled to 4096^2 (a photographic
+                    histogram: 2970 bins, sorted-by-yDiff queue, 64x64 tiles, generic dither kernel); the PCIe-inclusive rate of
+                    nq_convert_batch over page-locked host buffers (never the headline `value`);
   amortised_ms_per_image -- the three phases of a batch call (HIP events on the launch stream) divided by the batch size;
   cpu_baseline   -- the CPU oracle (C restatement of the reference's sequential Java path, 1 core) on the SAME 4096x4096 image
                     and seed as slot 0 of the batch (--cpu-sample shrinks it; the size is in its "sample" field), rank 0, N=1 only.
@@ -72,6 +78,99 @@ def cpu_baseline(workload, sample):
 LOOKUP_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "lookup_traffic.json")
 
 
+def photo_image(W, H, slot=0):
+    """The reference's sample photograph (tests/golden/sample_495x438.npz: decoded pixels of app/src/main/res/drawable/sample.jpg) tiled to
+    W x H; slot k adds k % 7 to the red channel (clipped) so that the images of a batch differ."""
+    rgb = np.load(os.path.join(ROOT, "tests", "golden", "sample_495x438.npz"))["rgb"].astype(np.uint32)
+    r = np.minimum(rgb[..., 0] + np.uint32(slot % 7), np.uint32(255))
+    a = ((np.uint32(255) << np.uint32(24)) | (r << np.uint32(16)) | (rgb[..., 1] << np.uint32(8)) | rgb[..., 2]).view(np.int32)
+    return np.ascontiguousarray(np.tile(a, (H // a.shape[0] + 1, W // a.shape[1] + 1))[:H, :W])
+
+
+def run_extras(nq, synth, slots, W, H, latency_ms, tile):
+    """Secondary measurements of the driver-run line (rank 0, N = 1, after the timed region); each is a few seconds."""
+    npx = W * H
+    out = {"single_image_mpixels_s": round(npx / (latency_ms * 1e-3) / 1e6, 2)}
+
+    def batch_rate(sl, steps, ins=None, warm=1):
+        qs = [s["q"] for s in sl]
+        ins = ins if ins is not None else [s["in"].data_ptr() for s in sl]
+        outs, idxs = [s["out"].data_ptr() for s in sl], [s["idx"].data_ptr() for s in sl]
+        for _ in range(warm):
+            nq.convert_batch_device(qs, ins, 256, True, outs, idxs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ph = {}
+        for _ in range(steps):
+            pals = nq.convert_batch_device(qs, ins, 256, True, outs, idxs)
+            for k, v in qs[0].batch_phase_ms().items():
+                ph[k] = ph.get(k, 0.0) + v / (steps * len(sl))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"batch": len(sl), "steps": steps, "mpixels_s": round(steps * len(sl) * npx / dt / 1e6, 1), "ms_per_image": round(dt / (steps * len(sl)) * 1e3, 3),
+                "amortised_ms_per_image": {k: round(v, 4) for k, v in ph.items()}, "maxbins": int(qs[0].params.maxbins), "palette": int(len(pals[0]))}
+
+    def single(q, d_in, s):
+        q.convert_device(d_in.data_ptr(), 256, True, s["out"].data_ptr(), s["idx"].data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        q.convert_device(d_in.data_ptr(), 256, True, s["out"].data_ptr(), s["idx"].data_ptr())
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    # 1. smaller batches of the headline images (the headline needs ~1024 merge loops side by side)
+    out["batch_sweep"] = [batch_rate(slots[:n], 2) for n in (64, 256) if n <= len(slots)]
+    # 2. BASELINE cfg 3 type (a): uniform random colours, every one of the 65 536 histogram bins occupied
+    nu = min(4, len(slots))
+    uni = [torch.from_numpy(synth.uniform_rgb(W, H, 3 + k).reshape(-1)).cuda() for k in range(nu)]
+    lat = single(slots[0]["q"], uni[0], slots[0])
+    st = slots[0]["q"].stage_ms()
+    nb = min(256, len(slots))
+    r = batch_rate(slots[:nb], 1, ins=[uni[k % nu].data_ptr() for k in range(nb)])
+    r.update({"workload": "%dx%d uniform random opaque colours (seeds 3..%d, cycled), PnnLABQuantizer.convert(256, true)" % (W, H, 2 + nu),
+              "single_convert_latency_ms": round(lat, 1), "single_image_mpixels_s": round(npx / (lat * 1e-3) / 1e6, 2),
+              "single_convert_stages_ms": {k: round(v, 3) for k, v in st.items()}})
+    out["cfg3a_uniform"] = r
+    del uni
+    # 3. a photographic histogram: the reference's sample picture tiled to the headline size
+    try:
+        nph = min(64, len(slots))
+        pho = [torch.from_numpy(photo_image(W, H, k).reshape(-1)).cuda() for k in range(min(7, nph))]
+        for s in slots[:nph]:
+            s["q"].set_tile(0, 0)            # automatic: 64x64 for the sorted-by-yDiff queue this histogram selects
+        lat = single(slots[0]["q"], pho[0], slots[0])
+        st = slots[0]["q"].stage_ms()
+        fast = slots[0]["q"].dither_path()[0]
+        r = batch_rate(slots[:nph], 1, ins=[pho[k % len(pho)].data_ptr() for k in range(nph)])
+        r.update({"workload": "the reference's sample.jpg (495x438 photograph) tiled to %dx%d, slot k: red + k %% 7; PnnLABQuantizer.convert(256, true)" % (W, H),
+                  "single_convert_latency_ms": round(lat, 1), "single_image_mpixels_s": round(npx / (lat * 1e-3) / 1e6, 2),
+                  "single_convert_stages_ms": {k: round(v, 3) for k, v in st.items()}, "specialised_dither_kernel": int(fast)})
+        out["photo"] = r
+        for s in slots[:nph]:
+            s["q"].set_tile(tile, tile)
+        del pho
+    except FileNotFoundError:
+        out["photo"] = None
+    # 4. PCIe-inclusive: nq_convert_batch over page-locked host buffers (uploads / read-backs overlap the per-image stages)
+    nh = min(128, len(slots))
+    sl = slots[:nh]
+    h_in = [s["in"].cpu().pin_memory() for s in sl]
+    h_out = [torch.empty(npx, dtype=torch.int32).pin_memory() for _ in sl]
+    h_idx = [torch.empty(npx, dtype=torch.int16).pin_memory() for _ in sl]
+    best = None
+    for it in range(2):
+        t0 = time.perf_counter()
+        pals = nq.convert_batch_host([s["q"] for s in sl], [t.data_ptr() for t in h_in], 256, True, [t.data_ptr() for t in h_out], [t.data_ptr() for t in h_idx])
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    ok = bool((torch.from_numpy(pals[0])[(h_idx[0].to(torch.int64) & 0xFFFF)] == h_out[0]).all())
+    out["host_batch"] = {"what": "nq_convert_batch: %d images of %dx%d in page-locked HOST memory, 10 B/pixel over PCIe (4 in, 4 + 2 out), copies overlapped "
+                                 "with the per-image stages; PCIe-inclusive, NOT the headline" % (nh, W, H),
+                         "batch": nh, "mpixels_s": round(nh * npx / best / 1e6, 1), "seconds": round(best, 3), "gb_moved": round(nh * npx * 10 / 1e9, 1),
+                         "outputs_match_palette": ok}
+    return out
+
+
 def measured_traffic(w, h, path=None):
     """HBM bytes per gilbert_kernel launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
     `bench.py --steps 1 --concurrency 1`, summaries under profiles/): 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
@@ -114,7 +213,8 @@ def main():
                     help="BASELINE.json configuration: cfg3 = the headline (4096^2 batches), cfg4 = 64 x 1920x1080 frames sharded over the "
                          "ranks, cfg5 = one 16384^2 image in row bands with the RCCL histogram exchange")
     ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform"])
+    ap.add_argument("--workload", default="gradient_noise", choices=["gradient_noise", "uniform", "photo"],
+                    help="gradient_noise = BASELINE cfg 3 type (b), the headline; uniform = type (a), 65 536 bins; photo = the reference's sample.jpg tiled to --size")
     ap.add_argument("--tile", type=int, default=0, help="tile side of the PARALLEL_TILED decomposition (0 = automatic)")
     ap.add_argument("--cpu-sample", type=int, default=4096,
                     help="side of the CPU-baseline image (default: the headline's own 4096, ~80 s on one core; 0 = skip)")
@@ -126,6 +226,7 @@ def main():
     ap.add_argument("--concurrency", type=int, default=1,
                     help="host threads / HIP streams a step's batch is split over (measured: one call for the whole batch is best -- the "
                          "library then runs 128-thread merge workgroups, four per CU, and the per-pixel stages have the chip to themselves)")
+    ap.add_argument("--no-extras", action="store_true", help="skip batch_sweep / cfg3a_uniform / photo / host_batch (N = 1 only, after the timed region)")
     ap.add_argument("--stagger", type=float, default=0.0,
                     help="with --concurrency T > 1: host thread t starts its first batch t * stagger seconds late, so that the merge loops of "
                          "one sub-batch (which leave most issue slots idle) run while another sub-batch is in its per-pixel stages")
@@ -189,11 +290,13 @@ def main():
     uniform = None
     if args.workload == "uniform":
         uniform = [torch.from_numpy(synth.uniform_rgb(W, H, 3 + rank * 8 + k).reshape(-1)).cuda() for k in range(min(8, Bn))]
+    elif args.workload == "photo":
+        uniform = [torch.from_numpy(photo_image(W, H, k).reshape(-1)).cuda() for k in range(min(7, Bn))]
     for b in range(Bn):
         seed = 3 + rank * Bn + b
         d_in = synth.gradient_noise_torch(W, H, seed) if uniform is None else uniform[b % len(uniform)]
         q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), device=local_rank, mode=nq.MODE_PARALLEL_TILED, seed=seed,
-                               tile=(tile, tile))
+                               tile=None if (args.workload == "photo" and args.tile <= 0) else (tile, tile))
         q.width, q.height = W, H
         slots.append({"q": q, "in": d_in, "out": torch.empty(npx, dtype=torch.int32, device="cuda"),
                       "idx": torch.empty(npx, dtype=torch.int16, device="cuda")})
@@ -282,7 +385,7 @@ def main():
         palt = torch.from_numpy(pals[k]).cuda()
         if len(pals[k]) != 256 or not bool((palt[(sk["idx"].to(torch.int64) & 0xFFFF)] == sk["out"]).all()):
             raise SystemExit("bench: output pixels of image %d do not match palette[index]" % k)
-    if len(g0["slots"]) > 1 and bool((pals[0] == pals[-1]).all()):
+    if len(g0["slots"]) > 1 and args.workload == "gradient_noise" and bool((pals[0] == pals[-1]).all()):
         raise SystemExit("bench: distinct images produced identical palettes")
 
     # LOOKUP_ONLY (nearestColorIndex per pixel, no diffusion) on slot 0 with its palette: the HBM-streaming kernel of the path
@@ -334,7 +437,9 @@ def main():
         LOOKUP_BYTES = 10          # 4 B ARGB read + 2 B index + 4 B ARGB written
         if lookup_ms and lookup_ms > 0:
             la = LOOKUP_BYTES * npx / (lookup_ms * 1e-3) / 1e9
-            line["roofline_lookup"] = {"bound": "hbm", "kernel": "fast_lookup_only_kernel (MODE_LOOKUP_ONLY: per-pixel nearestColorIndex, csrc/nq_dither_fast.hip)",
+            line["roofline_lookup"] = {"bound": "hbm", "kernel": "fast_lookup_pass1_kernel + fast_lookup_pass2_kernel (MODE_LOOKUP_ONLY: per-pixel nearestColorIndex, "
+                                                                 "csrc/nq_dither_fast.hip); algorithmic bytes exclude the deferred-pixel list between the passes; "
+                                                                 "traffic = PMC sum over both kernels",
                                        "achieved": round(la, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(la / HBM_PEAK_GBPS, 5),
                                        "traffic": measured_traffic(W, H, LOOKUP_TRAFFIC_FILE), "algorithmic_bytes_per_launch": LOOKUP_BYTES * npx,
                                        "kernel_ms": round(lookup_ms, 4),
@@ -343,6 +448,8 @@ def main():
         line["roofline_whole"] = {"bound": "hbm", "what": "8 B/pixel over the whole convert() of one image (all stages, batch amortised)",
                                   "achieved": round(BYTES_PER_PIXEL * npx / (whole_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": round(BYTES_PER_PIXEL * npx / (whole_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "ms_per_image": round(whole_ms, 3)}
+        if world == 1 and not args.no_extras and T == 1:
+            line.update(run_extras(nq, synth, slots, W, H, latency_ms, tile))
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
         else:

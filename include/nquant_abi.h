@@ -50,7 +50,10 @@ enum nq_status {
     NQ_ERR_HIP = -2,              /* HIP runtime error (text in nq_last_error) */
     NQ_ERR_UNSUPPORTED = -3,      /* a reference branch this build does not run on the GPU yet */
     NQ_ERR_REFERENCE_THROWS = -4, /* the Java code would throw here (e.g. setAlphaComponent range) */
-    NQ_ERR_NO_DEVICE = -5
+    NQ_ERR_NO_DEVICE = -5,
+    NQ_ERR_TIME_LIMIT = -6        /* a merge loop ran into its wall-clock limit (slow / shared / time-sliced device): nothing was
+                                   * wrong with its state -- call again, or raise NQ_OPT_MERGE_WALL_SECONDS.  Distinct from
+                                   * NQ_ERR_UNSUPPORTED, which the loop's find_nn budget (maxbins^2/2 calls) or an empty heap report */
 };
 
 /* Scalars convert() derives and the later stages consume.  Same layout as the
@@ -100,6 +103,10 @@ int nq_set_band(nq_handle* h, int y0, int image_height);
 /* NQ_OPT_FAST_DITHER (default 1): run the specialised dither kernel (csrc/nq_dither_fast.inc) where the configuration allows
  * it (LAB, 32 < K <= 256, no semi-transparency, DITHER_MAX 25, PARALLEL_TILED); 0 = the generic kernel everywhere.  Same results. */
 #define NQ_OPT_FAST_DITHER 2
+/* NQ_OPT_MERGE_WALL_SECONDS (default 0 = automatic: 60 s + 1 ms per histogram bin and per merge loop sharing a compute unit with it):
+ * seconds of residency after which a merge loop of this handle's calls gives up with NQ_ERR_TIME_LIMIT.  Every loop of the persistent
+ * merge kernel is bounded; this bound only exists so that a corrupt heap cannot keep the GPU for hours. */
+#define NQ_OPT_MERGE_WALL_SECONDS 3
 int nq_set_option(nq_handle* h, int option, int value);
 /* Diagnostics of the last dither pass: out_fast = 1 if the specialised kernel ran; out_failed_tiles = tiles it handed back to
  * the generic kernel (synchronises the handle's stream). */
@@ -233,7 +240,11 @@ int nq_band_color_presence_device(nq_handle* h, const uint32_t* d_argb, int64_t 
                                   int64_t* out_other_count, uint32_t* out_other);
 
 /* Wall-clock of the stages of the last nq_convert*_ call on this handle, milliseconds, measured with HIP
- * events on the handle's stream: {prescan, histogram, nn_init, merge, palette_fill, dither, bluenoise, total}. */
+ * events on the handle's stream: {prescan, histogram, nn_init, merge, palette_fill, dither, bluenoise, total}.
+ * Batch entry points: an event record costs the GPU ~3 us of queue time, so only the first SIXTEEN handles of a batch record all
+ * eight boundaries; for the others {prescan, histogram, nn_init, merge, palette_fill, bluenoise} are reported as -1 (not recorded),
+ * `dither` is the per-pixel pass as for every handle, and `total` spans from the start of the image's pre-scan to the END OF THE
+ * DITHER PASS -- it leaves out the BlueNoise post-pass of convert(n, false).  nq_get_batch_phase_ms gives the amortised phases. */
 #define NQ_N_STAGES 8
 int nq_get_stage_ms(const nq_handle* h, float* out8);
 /* Counters of the last merge loop (diagnostics), 16 values: {find_nn calls, merges, 100 MHz ticks inside find_nn, ticks in

@@ -164,6 +164,10 @@ struct nq_handle {
     DevBuf<long long> d_scalars;      // [0] rng state, [1..3] scan3, [4..19] merge stats, [20..21] distinct-colour result, [24..39] team counters, [40] palette status
     DevBuf<int> live3;                // merge loop: two live lists + position index
     int use_lists = 1;
+    int n_cus = 256;                  // compute units of the device (hipDeviceAttributeMultiprocessorCount): sizes merge workgroups / teams
+    int merge_wall_s = 0;             // NQ_OPT_MERGE_WALL_SECONDS: watchdog of a merge loop, seconds of residency (0 = automatic)
+    hipStream_t palette_stream = nullptr;   // stream the upload behind dev_palette was enqueued on ...
+    bool palette_synced = false;            // ... unless the host has waited for d_palette's content since (then any stream may read it)
     // nq_gilbert_dither / nq_bluenoise_dither: the static entry points of the reference run the same stages with caller-supplied
     // saliencies / weight instead of the ones dither() derives
     struct StageOverride { bool gilbert_only = false, blue_only = false; const float* d_sal = nullptr; bool hasSal = false; double weight = 0; float blueWeight = 1.f; } ov;
@@ -212,6 +216,13 @@ struct nq_handle {
     }
 };
 
+// what the launches since the last check left behind: a failed hipFuncSetAttribute of a launch_* function (kept per thread by
+// nq_kernels.hip) or the runtime's own last error
+static inline hipError_t launch_status() {
+    const hipError_t a = nq::take_launch_error(), b = hipGetLastError();
+    return a != hipSuccess ? a : b;
+}
+
 #define NQ_FAIL(h, code, ...) do { char _b[512]; std::snprintf(_b, sizeof _b, __VA_ARGS__); (h)->err = _b; return (code); } while (0)
 #define NQ_HIP(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
     NQ_FAIL(h, NQ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
@@ -228,7 +239,10 @@ int use_device(nq_handle* h) {
         }
         upload_tables(gamma, std::exp(1.5), std::exp(1.75), h->stream);
         upload_tables_fast(gamma, std::exp(1.5), std::exp(1.75), h->stream);
-        NQ_HIP(h, hipGetLastError());
+        NQ_HIP(h, launch_status());
+        int cus = 0;
+        NQ_HIP(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        if (cus > 0) h->n_cus = cus;
         NQ_HIP(h, h->d_scalars.reserve(64));
         NQ_HIP(h, h->d_ints.reserve(8 + 64));
         NQ_HIP(h, h->d_bincache.reserve(65536));
@@ -258,10 +272,13 @@ int upload_palette(nq_handle* h, const uint32_t* palette, int K) {
     const size_t cap = h->d_palette.n;
     NQ_HIP(h, h->d_palette.reserve((size_t) std::max(K, 2)));
     if (h->d_palette.n != cap) h->dev_palette.clear();          // (a new allocation)
-    if ((int) h->dev_palette.size() == K && std::memcmp(h->dev_palette.data(), palette, (size_t) K * sizeof(uint32_t)) == 0) return NQ_OK;
+    // (an earlier upload is ordered only against work on the stream it was enqueued on: after nq_set_stream the copy is repeated)
+    const bool ordered = h->palette_synced || h->palette_stream == h->stream;
+    if (ordered && (int) h->dev_palette.size() == K && std::memcmp(h->dev_palette.data(), palette, (size_t) K * sizeof(uint32_t)) == 0) return NQ_OK;
     h->dev_palette.clear();
     NQ_HIP(h, hipMemcpyAsync(h->d_palette.p, palette, K * sizeof(int), hipMemcpyHostToDevice, h->stream));
     h->dev_palette.assign(palette, palette + K);
+    h->palette_stream = h->stream; h->palette_synced = false;
     return NQ_OK;
 }
 void* packed_lists(nq_handle* h) { return h->sc->cell_lists.p + 2 * (size_t) 65536 * 32 + 2 * 65536; }
@@ -355,7 +372,7 @@ int distinct_colors(nq_handle* h, const uint32_t* d_argb, int64_t n, int64_t cap
     unsigned long long res[2] = {0, 0};
     NQ_HIP(h, hipMemcpyAsync(res, d_out, sizeof res, hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
-    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, launch_status());
     *out_count = (int64_t) res[0];
     if (want && (int64_t) res[0] <= cap) {
         std::vector<unsigned long long> heads(res[0]);
@@ -551,17 +568,24 @@ int merge_launch(nq_handle* owner, const PaletteJob* const* jobs, int n) {
     // workgroups that evaluate find_nn speculatively (nq_merge.inc); their hand-off words start zeroed.  The two kinds run one after
     // the other on this stream, so each is sized on its own.
     const int n_rgb = (int) host.size() - n_lab;
-    const int helpers_lab = nq::merge_team_helpers(n_lab, (int) host.size()), helpers_rgb = nq::merge_team_helpers(n_rgb, (int) host.size());
+    const int helpers_lab = nq::merge_team_helpers(n_lab, (int) host.size(), owner->n_cus),
+              helpers_rgb = nq::merge_team_helpers(n_rgb, (int) host.size(), owner->n_cus);
+    // watchdog (stats[14] = 2 -> NQ_ERR_TIME_LIMIT): seconds of RESIDENCY a loop may take.  Automatic: 60 s + 1 ms per bin and per loop that
+    // shares a CU with it (the slowest legitimate loop measured -- 65 536 bins, four loops per CU -- takes < 10 s; a time-sliced or
+    // shared device is slower, hence the margin and NQ_OPT_MERGE_WALL_SECONDS)
+    const int per_cu = std::max(1, ((int) host.size() + owner->n_cus - 1) / owner->n_cus);
     for (int i = 0; i < (int) host.size(); ++i) {
+        const long long secs = owner->merge_wall_s > 0 ? owner->merge_wall_s : 60LL + ((long long) host[i].maxbins * per_cu) / 1000;
+        host[i].wall_ticks = secs * 100000000LL;
         host[i].helpers = i < n_lab ? helpers_lab : helpers_rgb;
         if (host[i].helpers > 0) NQ_HIP(owner, hipMemsetAsync(host[i].team, 0, 256 * sizeof(unsigned long long), owner->stream));
     }
     NQ_HIP(owner, owner->d_jobs.reserve(host.size()));
     NQ_HIP(owner, hipMemcpyAsync(owner->d_jobs.p, host.data(), host.size() * sizeof(nq::MergeJob), hipMemcpyHostToDevice, owner->stream));
     NQ_HIP(owner, hipStreamSynchronize(owner->stream));    // `host` goes out of scope
-    launch_merge(1, owner->d_jobs.p, n_lab, (int) host.size(), helpers_lab, owner->stream);
-    launch_merge(0, owner->d_jobs.p + n_lab, n_rgb, (int) host.size(), helpers_rgb, owner->stream);
-    NQ_HIP(owner, hipGetLastError());
+    NQ_HIP(owner, launch_merge(1, owner->d_jobs.p, n_lab, (int) host.size(), owner->n_cus, helpers_lab, owner->stream));
+    NQ_HIP(owner, launch_merge(0, owner->d_jobs.p + n_lab, n_rgb, (int) host.size(), owner->n_cus, helpers_rgb, owner->stream));
+    NQ_HIP(owner, launch_status());
     return NQ_OK;
 }
 
@@ -579,9 +603,12 @@ int palette_check(nq_handle* h, const PaletteJob& job, int status, int32_t* out_
     std::memcpy(h->merge_stats, h->merge_readback, sizeof h->merge_stats);
     std::memcpy(h->team_stats, h->merge_readback + 20, sizeof h->team_stats);
     status = (int) (h->merge_readback[36] & 0xFFFFFFFFLL);
-    if (h->fetched_palette) h->dev_palette.assign(h->fetched_palette, h->fetched_palette + h->fetched_len);
+    if (h->fetched_palette) { h->dev_palette.assign(h->fetched_palette, h->fetched_palette + h->fetched_len); h->palette_synced = true; }   // (read back and waited for)
     h->fetched_palette = nullptr;
-    if (h->merge_stats[14]) NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "merge loop stopped by its watchdog (more than maxbins^2/2 find_nn calls, 240 s of wall clock, or an empty heap)");
+    if (h->merge_stats[14] == 2)
+        NQ_FAIL(h, NQ_ERR_TIME_LIMIT, "merge loop stopped at its time limit (a slow, shared or time-sliced device: the state was sound; call again, or "
+                                      "raise NQ_OPT_MERGE_WALL_SECONDS)");
+    if (h->merge_stats[14]) NQ_FAIL(h, NQ_ERR_UNSUPPORTED, "merge loop stopped by its watchdog (more than maxbins^2/2 find_nn calls, or an empty heap)");
     if (status) NQ_FAIL(h, NQ_ERR_REFERENCE_THROWS, "ColorUtils.setAlphaComponent: alpha outside 0..255 (the reference throws IllegalArgumentException)");
     h->params.paletteLength = job.plen;
     *out_K = job.plen;
@@ -592,7 +619,7 @@ int palette_finish(nq_handle* h, const PaletteJob& job, uint32_t* out_palette, i
     int rc = palette_fetch(h, job, out_palette, &status);
     if (rc) return rc;
     NQ_HIP(h, hipStreamSynchronize(h->stream));
-    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, launch_status());
     return palette_check(h, job, status, out_K);
 }
 
@@ -693,7 +720,7 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         else
             launch_lookup_only(P, h->d_palette.p, lv, (const int*) d_argb, n, d_out_index, (int*) d_out_argb, h->stream);
         rec(h, 6); rec(h, 7);
-        NQ_HIP(h, hipGetLastError());
+        NQ_HIP(h, launch_status());
         h->dither_events_fresh = true;
         return NQ_OK;
     }
@@ -838,7 +865,7 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
         launch_bluenoise(P, h->d_palette.p, lv, (const int*) d_argb, width, height, T.y_origin, blueWeight, (long long) seed, sequential ? 1 : 0,
                          h->d_bincache.p, h->d_scalars.p, d_out_index, (int*) d_out_argb, h->stream);
     rec(h, 7);
-    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, launch_status());
     h->dither_events_fresh = true;
     return NQ_OK;
 }
@@ -847,7 +874,7 @@ void finish_timing(nq_handle* h) {
     // {prescan, histogram, nn_init, merge, palette_fill, dither, bluenoise, total}
     for (int i = 0; i < 7; ++i) {
         float ms = 0;
-        if (h->light_events && i != 5) { h->stage_ms[i] = 0; continue; }          // (not recorded: see rec)
+        if (h->light_events && i != 5) { h->stage_ms[i] = -1.0f; continue; }      // (not recorded: see rec)
         if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = 0;
         h->stage_ms[i] = ms;
     }
@@ -935,6 +962,7 @@ int nq_set_option(nq_handle* h, int option, int value) {
     if (!h) return NQ_ERR_INVALID;
     if (option == NQ_OPT_CELL_LISTS) { h->use_lists = value != 0; return NQ_OK; }
     if (option == NQ_OPT_FAST_DITHER) { h->use_fast_dither = value != 0; return NQ_OK; }
+    if (option == NQ_OPT_MERGE_WALL_SECONDS) { h->merge_wall_s = value > 0 ? value : 0; return NQ_OK; }
     NQ_FAIL(h, NQ_ERR_INVALID, "unknown option %d", option);
 }
 int nq_selftest_ciede(nq_handle* h, const float* lab_pairs, int64_t n, uint32_t* out9) {
@@ -1190,7 +1218,7 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
             if (rc) return fail_from(hs[i], rc);
         }
     NQ_HIP(h0, hipStreamSynchronize(lane_s[0]));
-    NQ_HIP(h0, hipGetLastError());
+    NQ_HIP(h0, launch_status());
     for (int i = 0; i < n; ++i)
         if (jobs[i].merge) {
             rc = palette_check(hs[i], jobs[i], pal_status[i], out_K + i);
@@ -1343,7 +1371,7 @@ int nq_nearest_index(nq_handle* h, const uint32_t* palette, int K, const uint32_
         launch_fast_nearest_index(P, lv, h->d_palette.p, packed_lists(h), h->d_colors.p, M, h->d_short.p, h->stream);
     else
         launch_nearest_index(P, h->d_palette.p, lv, h->d_colors.p, M, h->d_short.p, h->stream);
-    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, launch_status());
     NQ_HIP(h, hipMemcpyAsync(out_index, h->d_short.p, (size_t) M * sizeof(short), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
     return NQ_OK;
@@ -1366,7 +1394,7 @@ int nq_closest_tuple(nq_handle* h, const uint32_t* palette, int K, const uint32_
         launch_fast_closest_tuple(P, lv, h->d_palette.p, packed_lists(h), h->d_colors.p, M, h->d_tuple.p, h->stream);
     else
         launch_closest_tuple(P, h->d_palette.p, lv, h->d_colors.p, M, h->d_tuple.p, h->stream);
-    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, launch_status());
     NQ_HIP(h, hipMemcpyAsync(out_closest4, h->d_tuple.p, (size_t) 4 * M * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
     return NQ_OK;
@@ -1379,7 +1407,7 @@ int nq_band_scan_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pixels, 
     if (!d_argb || n_pixels <= 0 || !d_scan3) NQ_FAIL(h, NQ_ERR_INVALID, "bad argument");
     (void) nMaxColors;
     launch_prescan((const int*) d_argb, n_pixels, index_offset, (long long*) d_scan3, h->stream);
-    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, launch_status());
     return NQ_OK;
 }
 
@@ -1413,7 +1441,7 @@ int nq_band_color_presence_device(nq_handle* h, const uint32_t* d_argb, int64_t 
     unsigned* d_set = h->sc->dk_a.p;
     unsigned* d_cnt = d_set + slots;
     launch_color_presence((const int*) d_argb, n_pixels, h->params.transparentColor, d_presence, d_set, slots, d_cnt, h->stream);
-    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, launch_status());
     unsigned cnt[2] = {0, 0};
     NQ_HIP(h, hipMemcpyAsync(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
     NQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -1453,7 +1481,7 @@ int nq_band_histogram_device(nq_handle* h, const uint32_t* d_argb, int64_t n_pix
     ws.keys_a = h->sc->keys_a.p; ws.keys_b = h->sc->keys_b.p; ws.vals_a = h->sc->vals_a.p; ws.vals_b = h->sc->vals_b.p;
     ws.tmp = h->sc->sort_tmp.p; ws.tmp_bytes = h->sc->sort_tmp.n; ws.seg_start = h->sc->seg.p; ws.seg_end = h->sc->seg.p + 65536;
     launch_histogram(h->kind, (const int*) d_argb, n_pixels, hp, ws, d_hist, h->stream);
-    NQ_HIP(h, hipGetLastError());
+    NQ_HIP(h, launch_status());
     return NQ_OK;
 }
 

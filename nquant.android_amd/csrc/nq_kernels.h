@@ -159,13 +159,20 @@ struct MergeJob {
     int plen; int* palette; int* status;   // P10 runs at the end of the merge workgroup: palette[plen], status |= 1 where Java throws
     // merge teams (launch_merge decides): 256 u64 of zeroed device memory per job for the work records / results of the helpers
     unsigned long long* team; int helpers;
+    long long wall_ticks;       // watchdog: the loop stops (stats[14] = 2) after this many 100 MHz ticks of residency
 };
 // d_jobs: n jobs of one kind in device memory, one workgroup per job.  n_in_flight = merge loops expected to run at the same
-// time on the device (the whole batch): <= 256 -> 512-thread workgroups, one per CU; <= 512 -> 256 threads, two per CU;
-// more -> 128 threads, four per CU.  helpers > 0 (either kind, 512-thread variant only; every job's `team` area zeroed and `helpers` set to
-// the same number): the grid holds 1 + helpers workgroups per job (merge teams, nq_merge.inc).
-void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int helpers, hipStream_t s);
-// helpers launch_merge would use for n jobs of one kind when n_in_flight loops share the device (0..7; NQ_MERGE_HELPERS overrides)
-int merge_team_helpers(int n_jobs, int n_in_flight);
+// time on the device (the whole batch), n_cus = compute units of the handle's device (hipDeviceAttributeMultiprocessorCount: 256 on an
+// unpartitioned MI355X): <= n_cus -> 512-thread workgroups, one per CU; <= 2 n_cus -> 256 threads, two per CU; more -> 128 threads, four
+// per CU.  helpers > 0 (either kind, 512-thread variant only; every job's `team` area zeroed and `helpers` set to
+// the same number): the grid holds 1 + helpers workgroups per job (merge teams, nq_merge.inc).  Returns the first HIP error of the
+// attribute call / launch.
+hipError_t launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int n_cus, int helpers, hipStream_t s);
+// helpers launch_merge would use for n jobs of one kind when n_in_flight loops share a device of n_cus compute units (0..7;
+// NQ_MERGE_HELPERS overrides).  Sized on THIS call's jobs: merge launches of other handles / threads on the same device are not
+// counted -- correctness does not depend on it (every wait of a team is bounded, nq_merge.inc), only the speed-up does.
+int merge_team_helpers(int n_jobs, int n_in_flight, int n_cus);
+// first error of a hipFuncSetAttribute issued by a launch_* function on this thread since the last call (hipSuccess: none); cleared
+hipError_t take_launch_error();
 
 } // namespace nq

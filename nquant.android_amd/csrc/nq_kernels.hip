@@ -35,9 +35,12 @@ static inline int grid_for(int64_t n, int block, int cap = 256 * 8) {
 
 // kernels that stage a K-entry palette (+ its Lab) in dynamic LDS: above 64 KB (LAB palettes beyond ~3700 entries, up to the
 // documented 8192) the launch needs the raised per-kernel limit
+static thread_local hipError_t t_launch_error = hipSuccess;
+static inline void note_error(hipError_t e) { if (e != hipSuccess && t_launch_error == hipSuccess) t_launch_error = e; }
+hipError_t take_launch_error() { const hipError_t e = t_launch_error; t_launch_error = hipSuccess; return e; }
 template <typename Kern>
 static inline void allow_big_lds(Kern kernel, size_t bytes) {
-    if (bytes > 48 * 1024) (void) hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+    if (bytes > 48 * 1024) note_error(hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
 }
 
 static inline CellLists to_lists(const ListsView& v) {
@@ -245,21 +248,27 @@ void launch_find_nn_init(const NNParams& np, const Bins& B, int maxbins, float* 
 }
 // one workgroup per job; the workgroup size follows the number of jobs in flight (nq_merge.inc)
 template <typename K>
-static void launch_merge_variant(K kernel, size_t dyn, int threads, const MergeJob* d_jobs, int n, hipStream_t s, int n_pad = 0, int roles = 1) {
-    (void) hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
+static hipError_t launch_merge_variant(K kernel, size_t dyn, int threads, const MergeJob* d_jobs, int n, hipStream_t s, int n_pad = 0, int roles = 1) {
+    const hipError_t e = hipFuncSetAttribute((const void*) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(roles > 1 ? n_pad * roles : n), dim3(threads), dyn, s, d_jobs, n, n_pad);
+    return hipGetLastError();
 }
-static int merge_threads_for(int n_in_flight) {
+// XCDs of the device: workgroups are dealt out to them round-robin by blockIdx, so a team whose members share blockIdx % NQ_XCDS shares
+// an L2.  There is no HIP attribute for it (gfx950: 8); a different count only costs the teams their shared L2, never a result.
+#define NQ_XCDS 8
+static int merge_threads_for(int n_in_flight, int n_cus) {
     if (const char* f = std::getenv("NQ_MERGE_THREADS")) {       // tests: force one variant (512, 256 or 128)
         const int t = std::atoi(f);
         if (t == 128 || t == 256 || t == 512) return t;
     }
-    return n_in_flight <= 256 ? 512 : n_in_flight <= 512 ? 256 : 128;
+    if (n_cus < 1) n_cus = 1;
+    return n_in_flight <= n_cus ? 512 : n_in_flight <= 2 * n_cus ? 256 : 128;
 }
-int merge_team_helpers(int n_jobs, int n_in_flight) {
-    if (n_jobs <= 0 || merge_threads_for(n_in_flight) != 512) return 0;
-    const int n_pad = (n_jobs + 7) / 8 * 8;
-    int h = 256 / n_pad - 1;                       // one 512-thread workgroup per CU, 256 CUs
+int merge_team_helpers(int n_jobs, int n_in_flight, int n_cus) {
+    if (n_jobs <= 0 || merge_threads_for(n_in_flight, n_cus) != 512) return 0;
+    const int n_pad = (n_jobs + NQ_XCDS - 1) / NQ_XCDS * NQ_XCDS;
+    int h = n_cus / n_pad - 1;                     // one 512-thread workgroup per CU
     if (h > 7) h = 7;
     if (h < 0) h = 0;
     if (const char* f = std::getenv("NQ_MERGE_HELPERS")) {       // tests / measurements: 0 = the single-workgroup loop
@@ -268,23 +277,23 @@ int merge_team_helpers(int n_jobs, int n_in_flight) {
     }
     return h;
 }
-void launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int helpers, hipStream_t s) {
-    if (n <= 0) return;
-    const int threads = merge_threads_for(n_in_flight);
+hipError_t launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int n_cus, int helpers, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int threads = merge_threads_for(n_in_flight, n_cus);
     if (threads == 512) {
         if (helpers > 0) {
-            const int n_pad = (n + 7) / 8 * 8;
-            if (kind == 1) launch_merge_variant(m512::merge_kernel<1, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
-            else launch_merge_variant(m512::merge_kernel<0, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
+            const int n_pad = (n + NQ_XCDS - 1) / NQ_XCDS * NQ_XCDS;
+            if (kind == 1) return launch_merge_variant(m512::merge_kernel<1, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
+            return launch_merge_variant(m512::merge_kernel<0, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
         }
-        else if (kind == 1) launch_merge_variant(m512::merge_kernel<1>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
-        else launch_merge_variant(m512::merge_kernel<0>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
-    } else if (threads == 256) {
-        if (kind == 1) launch_merge_variant(m256::merge_kernel<1>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
-        else launch_merge_variant(m256::merge_kernel<0>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
-    } else {
-        if (kind == 1) launch_merge_variant(m128::merge_kernel<1>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
-        else launch_merge_variant(m128::merge_kernel<0>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
+        if (kind == 1) return launch_merge_variant(m512::merge_kernel<1>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
+        return launch_merge_variant(m512::merge_kernel<0>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
     }
+    if (threads == 256) {
+        if (kind == 1) return launch_merge_variant(m256::merge_kernel<1>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
+        return launch_merge_variant(m256::merge_kernel<0>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
+    }
+    if (kind == 1) return launch_merge_variant(m128::merge_kernel<1>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
+    return launch_merge_variant(m128::merge_kernel<0>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
 }
 } // namespace nq

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "nq_band_histogram_device", "nq_palette_from_histograms_device", "nq_band_distinct_device", "nq_set_distinct", "nq_get_stage_ms", "nq_get_merge_stats",
     "nq_get_dither_path", "nq_get_batch_phase_ms", "nq_get_team_stats", "nq_set_band", "nq_band_color_presence_device", "nq_gilbert_dither", "nq_bluenoise_dither", "nq_selftest_ciede",
 ]
-OPT_CELL_LISTS, OPT_FAST_DITHER = 1, 2
+OPT_CELL_LISTS, OPT_FAST_DITHER, OPT_MERGE_WALL_SECONDS = 1, 2, 3
 
 
 def abi_symbols():

@@ -29,12 +29,15 @@ def uniform_rgb(width, height, seed):
     return (rgb | np.uint32(0xFF000000)).view(np.int32).reshape(height, width)
 
 
-def gradient_noise(width, height, seed, noise=24):
+def gradient_noise(width, height, seed, noise=24, row0=0, rows=None):
     """type (b): smooth 2-D gradients + per-channel noise, opaque.  R follows x, G follows y, B follows a diagonal
-    wave; `noise` is the peak-to-peak amplitude of the uniform per-channel noise (8-bit units)."""
-    n = width * height
-    z = splitmix64(seed, n)
-    y, x = np.divmod(np.arange(n, dtype=np.int64), width)
+    wave; `noise` is the peak-to-peak amplitude of the uniform per-channel noise (8-bit units).  With row0 / rows only the rows
+    [row0, row0 + rows) of that image (large images are produced band by band)."""
+    if rows is None:
+        rows = height - row0
+    n = width * rows
+    z = splitmix64(seed, n, offset=row0 * width)
+    y, x = np.divmod(np.arange(n, dtype=np.int64) + row0 * width, width)
     fx = x / max(width - 1, 1)
     fy = y / max(height - 1, 1)
     nr = ((z >> np.uint64(0)) & np.uint64(0xFF)).astype(np.float64) / 255.0 - 0.5
@@ -47,7 +50,16 @@ def gradient_noise(width, height, seed, noise=24):
     g = np.clip(np.rint(g), 0, 255).astype(np.uint32)
     b = np.clip(np.rint(b), 0, 255).astype(np.uint32)
     a = np.full(n, 255, np.uint32)
-    return _pack(a, r, g, b).reshape(height, width)
+    return _pack(a, r, g, b).reshape(rows, width)
+
+
+def gradient_noise_banded(width, height, seed, band_rows=1024):
+    """gradient_noise() of a large image, produced band by band (the float64 temporaries of 2^28 pixels at once would need ~25 GB)."""
+    out = np.empty((height, width), np.int32)
+    for r0 in range(0, height, band_rows):
+        rr = min(band_rows, height - r0)
+        out[r0:r0 + rr] = gradient_noise(width, height, seed, row0=r0, rows=rr)
+    return out
 
 
 def with_alpha(img, seed, p_transparent=0.01, p_semi=0.05):
@@ -68,6 +80,17 @@ def few_colors(width, height, seed, ncolors):
     z = splitmix64(seed, width * height)
     pal = (splitmix64(seed ^ 0x5EED, ncolors) & np.uint64(0xFFFFFF)).astype(np.uint32) | np.uint32(0xFF000000)
     return pal[(z % np.uint64(ncolors)).astype(np.int64)].view(np.int32).reshape(height, width)
+
+
+def flat_with_patch(side, alpha, seed, patch=160, rgb=0x336698):
+    """A flat region of more than 2^24 pixels (for side >= 4100) whose colours differ only in the low three blue bits -- ONE histogram
+    bin under every key form, eight distinct colours -- plus a patch x patch gradient+noise square in the middle rows so that the image
+    has more bins than colours asked for.  Row T3 of SURVEY 8a: `cnt` is a float and `cnt++` stops at 16 777 216."""
+    z = splitmix64(seed, side * side)
+    img = (np.uint32((alpha << 24) | rgb) | (z & np.uint64(7)).astype(np.uint32)).view(np.int32).reshape(side, side).copy()
+    y0 = side // 2
+    img[y0:y0 + patch, 100:100 + patch] = gradient_noise(patch, patch, seed + 1)
+    return img
 
 
 def gradient_noise_torch(width, height, seed, device="cuda", noise=24, row0=0, rows=None):

@@ -46,6 +46,82 @@ LOOKUP_CASES = {
 }
 
 
+# The reference's only input asset, decoded (tools/extract_sample_pixels.py -> sample_495x438.npz, pixels only): the picture the demo
+# activity quantizes with `new PnnQuantizer(path).convert(256, true)` (app/src/main/java/nQuant/android/MainActivity.java:190-194) and
+# the README's `new PnnLABQuantizer(path).convert(256, true)`.  A photographic histogram: 2970 bins -> weight 0.086 (colour-keyed
+# caches, not isNano), quan_rt 1, GilbertCurve sorted-by-yDiff queue with DITHER_MAX 9 -- rungs no synthetic generator reaches at K = 256.
+# Per case: palette + scalars, the whole convert in REFERENCE_SEQUENTIAL mode, and the tiled decomposition (64x64 tiles: the automatic
+# rule for the sorted queue).
+def sample_image():
+    rgb = np.load(os.path.join(OUT, "sample_495x438.npz"))["rgb"].astype(np.uint32)
+    return ((np.uint32(255) << np.uint32(24)) | (rgb[..., 0] << np.uint32(16)) | (rgb[..., 1] << np.uint32(8)) | rgb[..., 2]).view(np.int32)
+
+
+SAMPLE_TILE = (64, 64)
+SAMPLE_CASES = {
+    "sample_rgb256_dither": dict(kind=0, K=256, dither=True, seed=7),
+    "sample_lab256_dither": dict(kind=1, K=256, dither=True, seed=7),
+    "sample_rgb256_nodither": dict(kind=0, K=256, dither=False, seed=7),
+    "sample_lab256_nodither": dict(kind=1, K=256, dither=False, seed=7),
+    "sample_lab16_dither": dict(kind=1, K=16, dither=True, seed=7),
+}
+
+
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8).copy()
+
+
+def run_sample_case(c):
+    img = sample_image()
+    q = O.OracleQuantizer(c["kind"], img, seed=c["seed"])
+    q.prescan(c["K"])
+    pal = q.pnnquan(c["K"])
+    p = q.params
+    scal = np.array([p.hasSemiTransparency, p.transparentPixelIndex, p.transparentColor, p.isNano, p.texicab, p.quan_rt,
+                     p.maxbins, p.paletteLength], np.int64)
+    dbl = np.array([p.PR, p.PG, p.PB, p.PA, p.ratio, p.weight], np.float64)
+    q.set_seed(c["seed"])
+    seq_argb, seq_idx = q.dither(pal, c["dither"])
+    distinct_seq = np.int64(q.params.distinctColors)
+    q2 = O.OracleQuantizer(c["kind"], img, seed=c["seed"])
+    q2.prescan(c["K"])
+    assert (q2.pnnquan(c["K"]) == pal).all()
+    q2.set_seed(c["seed"])
+    til_argb, til_idx = q2.dither(pal, c["dither"], tile=SAMPLE_TILE)
+    return dict(palette=pal, scalars=scal, doubles=dbl, seq_index=seq_idx.astype(np.uint8), seq_argb_sha256=_sha(seq_argb),
+                tiled_index=til_idx.astype(np.uint8), tiled_argb_sha256=_sha(til_argb), distinct_seq=distinct_seq,
+                distinct_tiled=np.int64(q2.params.distinctColors))
+
+
+# BASELINE cfg 5: 16384 x 16384 gradient + noise, seed 5, PnnLABQuantizer 256 colours: the palette and scalars of the WHOLE image
+# (2^28 pixels through the oracle's histogram: minutes of CPU time, so the fixture is produced here and not on the GPU box), plus
+# an order-sensitive checksum of the input so that the GPU-side test knows it quantizes the very same pixels.
+BIG_CASES = {
+    "cfg5_lab256_palette_16384x16384": dict(kind=1, K=256, width=16384, height=16384, seed=5),
+}
+
+
+def image_checksum(img):
+    """(sum, position-weighted sum) of the pixels as uint64, wrapping: cheap on the host and with torch on the device."""
+    with np.errstate(over="ignore"):
+        v = img.reshape(-1).view(np.uint32).astype(np.uint64)
+        w = (np.arange(v.size, dtype=np.uint64) & np.uint64(0xFFFF)) + np.uint64(1)
+        return np.array([v.sum(dtype=np.uint64), (v * w).sum(dtype=np.uint64)], np.uint64)
+
+
+def run_big_case(c):
+    img = synth.gradient_noise_banded(c["width"], c["height"], c["seed"])
+    q = O.OracleQuantizer(c["kind"], img)
+    q.prescan(c["K"])
+    pal = q.pnnquan(c["K"])
+    p = q.params
+    scal = np.array([p.hasSemiTransparency, p.transparentPixelIndex, p.transparentColor, p.isNano, p.texicab, p.quan_rt,
+                     p.maxbins, p.paletteLength], np.int64)
+    dbl = np.array([p.PR, p.PG, p.PB, p.PA, p.ratio, p.weight], np.float64)
+    return dict(palette=pal, scalars=scal, doubles=dbl, distinct=np.int64(p.distinctColors), checksum=image_checksum(img))
+
+
 def run_lookup_case(c):
     import hashlib
     img = c["img"]()
@@ -88,6 +164,15 @@ if __name__ == "__main__":
         r = run_case(c)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)
         print(name, "K", len(r["palette"]), "maxbins", int(r["scalars"][6]))
+    for name, c in SAMPLE_CASES.items():
+        r = run_sample_case(c)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)
+        print(name, "K", len(r["palette"]), "maxbins", int(r["scalars"][6]), "distinct", int(r["distinct_seq"]), int(r["distinct_tiled"]))
+    if "--big" in sys.argv:          # ~10 minutes, 4 GB
+        for name, c in BIG_CASES.items():
+            r = run_big_case(c)
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)
+            print(name, "K", len(r["palette"]), "maxbins", int(r["scalars"][6]), "distinct", int(r["distinct"]))
     for name, c in LOOKUP_CASES.items():
         r = run_lookup_case(c)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)

@@ -82,3 +82,41 @@ def test_synth_is_deterministic(nq):
     t = synth.with_alpha(g, 3)
     al = t.view(np.uint32) >> 24
     assert (al == 0).any() and ((al > 15) & (al < 0xE0)).any()
+
+
+def _java_natives(path):
+    """{name: number of parameters} of the `native` methods a Java host class declares."""
+    src = open(path).read()
+    out = {}
+    for m in re.finditer(r"\bnative\s+[\w\[\]\.]+\s+(\w+)\s*\(([^)]*)\)", src, re.S):
+        params = [p for p in m.group(2).split(",") if p.strip()]
+        out[m.group(1)] = len(params)
+    return out
+
+
+def test_jni_shim_matches_the_header_and_the_java_host_class():
+    """SURVEY 8f row 1 cannot run here (no JDK): what CAN be held is that the shim stays in step with the ABI it wraps.  (1) nquant_jni.c
+    passes `gcc -fsyntax-only -Wall -Werror` against include/nquant_abi.h and a stub of the few JNI declarations it uses
+    (tests/c/jni_syntax/jni.h -- not a JDK header, never linked): a changed nq_* signature breaks this test; (2) every `native` method of
+    the Java host class has its Java_com_android_nQuant_PnnQuantizer_<name> function with the same number of parameters (+ env, class),
+    and the reverse; (3) the Java class keeps the reference's public surface (constructor from a file name, convert(int, boolean)
+    throws Exception, hasAlpha(): NQ/PnnQuantizer.java:35,409,458)."""
+    import subprocess
+    shim = os.path.join(ROOT, "nquant.android_amd", "jni", "nquant_jni.c")
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "c", "jni_syntax"),
+                        "-I", os.path.join(ROOT, "include"), shim], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    java = os.path.join(ROOT, "nquant.android_amd", "java", "com", "android", "nQuant", "PnnQuantizer.java")
+    natives = _java_natives(java)
+    csrc = re.sub(r"/\*.*?\*/", "", open(shim).read(), flags=re.S)
+    cfuncs = {m.group(1): len([p for p in m.group(2).split(",") if p.strip()])
+              for m in re.finditer(r"Java_com_android_nQuant_PnnQuantizer_(\w+)\s*\(([^)]*)\)", csrc, re.S)}
+    assert sorted(natives) == sorted(cfuncs) and len(natives) >= 5
+    for name, n in natives.items():
+        assert cfuncs[name] == n + 2, (name, n, cfuncs[name])
+    jsrc = open(java).read()
+    assert re.search(r"public\s+PnnQuantizer\s*\(\s*String\s+\w+\s*\)", jsrc)
+    assert re.search(r"public\s+Bitmap\s+convert\s*\(\s*int\s+nMaxColors\s*,\s*boolean\s+dither\s*\)\s*throws\s+Exception", jsrc)
+    assert re.search(r"public\s+boolean\s+hasAlpha\s*\(\s*\)", jsrc)
+    lab = open(os.path.join(os.path.dirname(java), "PnnLABQuantizer.java")).read()
+    assert re.search(r"class\s+PnnLABQuantizer\s+extends\s+PnnQuantizer", lab) and re.search(r"public\s+PnnLABQuantizer\s*\(\s*String\s+\w+\s*\)", lab)

@@ -111,3 +111,58 @@ def test_gpu_cfg2_end_to_end_lookup_only(nq, name):
     assert (np.bincount(idx, minlength=len(out.palette)) == want["index_histogram"]).all()
     assert (np.frombuffer(hashlib.sha256(idx.tobytes()).digest(), np.uint8) == want["index_sha256"]).all()
     assert (out.argb.reshape(-1) == out.palette[idx]).all()
+
+
+# ---- the reference's own input asset (a photograph): tests/golden/sample_*.npz ----
+
+@pytest.mark.parametrize("name", sorted(mg.SAMPLE_CASES))
+def test_oracle_reproduces_golden_sample(name):
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    got = mg.run_sample_case(mg.SAMPLE_CASES[name])
+    for k in want.files:
+        assert (got[k] == want[k]).all(), (name, k)
+
+
+def _sample_quantizer(nq, c, mode, tile=None):
+    return (nq.PnnLABQuantizer if c["kind"] else nq.PnnQuantizer)(mg.sample_image(), mode=mode, seed=c["seed"], tile=tile)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(mg.SAMPLE_CASES))
+def test_gpu_sample_photo_whole_convert_sequential(nq, name):
+    """The app's real call on the app's real picture -- new PnnQuantizer(path).convert(256, true) (MainActivity.java:190-194), the
+    README's PnnLABQuantizer, their dither=false legs and a 16-colour LAB run -- as ONE convert() in REFERENCE_SEQUENTIAL mode (one
+    curve over the image, colour-keyed first-come caches: weight 0.086 > .015, one Random(seed)): palette, scalars, every index and
+    the ARGB bitmap equal the fixture."""
+    c = mg.SAMPLE_CASES[name]
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    q = _sample_quantizer(nq, c, nq.MODE_REFERENCE_SEQUENTIAL)
+    out = q.convert(c["K"], c["dither"])
+    assert len(out.palette) == len(want["palette"]) and (out.palette == want["palette"]).all()
+    p = q.params
+    assert [p.hasSemiTransparency, p.transparentPixelIndex, p.transparentColor, p.isNano, p.texicab, p.quan_rt, p.maxbins,
+            p.paletteLength] == list(want["scalars"])
+    assert (np.array([p.PR, p.PG, p.PB, p.PA, p.ratio, p.weight]) == want["doubles"]).all()
+    nbad = int((out.index != want["seq_index"]).sum())
+    assert nbad == 0, "%d of %d indices differ" % (nbad, out.index.size)
+    assert (mg._sha(out.argb) == want["seq_argb_sha256"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(mg.SAMPLE_CASES))
+def test_gpu_sample_photo_tiled(nq, name):
+    """The same calls in the production mode (PARALLEL_TILED): 64x64 tiles, ragged at the right and bottom edges (495 x 438), against
+    the oracle's tiled restatement held by the fixture; for the 256-colour cases (sorted-by-yDiff queue) the automatic tile rule must
+    choose exactly this decomposition."""
+    c = mg.SAMPLE_CASES[name]
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    q = _sample_quantizer(nq, c, nq.MODE_PARALLEL_TILED, tile=mg.SAMPLE_TILE)
+    out = q.convert(c["K"], c["dither"])
+    assert (out.palette == want["palette"]).all()
+    nbad = int((out.index != want["tiled_index"]).sum())
+    assert nbad == 0, "%d of %d indices differ" % (nbad, out.index.size)
+    assert (mg._sha(out.argb) == want["tiled_argb_sha256"]).all()
+    if c["K"] > 128:
+        q2 = _sample_quantizer(nq, c, nq.MODE_PARALLEL_TILED)
+        out2 = q2.convert(c["K"], c["dither"])
+        assert (out2.index == out.index).all() and (out2.argb == out.argb).all()

@@ -336,3 +336,65 @@ def test_cfg5_16384_properties_and_eight_bands(nq):
     q.dither_device(d_in.data_ptr(), bpal, True, d_out.data_ptr(), d_idx.data_ptr())
     torch.cuda.synchronize()
     assert bool((b_idx == d_idx).all()) and bool((b_out == d_out).all()), "8 dithered bands != the whole image dithered with the same palette"
+
+
+def _torch_checksum(t):
+    """make_golden.image_checksum on a device tensor (int64 arithmetic wraps like the uint64 sums of the fixture)."""
+    import torch
+    v = t.to(torch.int64) & 0xFFFFFFFF
+    w = (torch.arange(v.numel(), dtype=torch.int64, device=t.device) & 0xFFFF) + 1
+    s0, s1 = int(v.sum().item()), int((v * w).sum().item())
+    return np.array([s0 & 0xFFFFFFFFFFFFFFFF, s1 & 0xFFFFFFFFFFFFFFFF], np.uint64)
+
+
+def test_cfg5_16384_palette_and_tile_rows_vs_oracle(nq, oracle):
+    """BASELINE cfg 5 at FULL size against the oracle, not against the GPU itself: the palette and scalars of the 2^28-pixel image
+    equal the committed fixture (tests/golden/cfg5_lab256_palette_16384x16384.npz: the oracle's whole-image pnnquan, produced in the build
+    container by make_golden.py --big -- minutes of CPU time), and three tile rows of the dithered output (first, middle, last:
+    3 x 2048 tiles of 8x8) equal the oracle's tiled restatement run here (nqo_dither_tile_rows with the fixture's palette and scalars).
+    The input is identified by a checksum held in the fixture; if the device-generated image differs from it in a single pixel (a
+    device sin() on a rounding boundary) the image is regenerated with numpy."""
+    import torch
+    want = np.load(os.path.join(ROOT, "tests", "golden", "cfg5_lab256_palette_16384x16384.npz"))
+    W = H = 16384
+    seed = 5
+    d_in = synth.gradient_noise_torch(W, H, seed)
+    torch.cuda.synchronize()
+    if not (_torch_checksum(d_in) == want["checksum"]).all():
+        img = synth.gradient_noise_banded(W, H, seed)
+        d_in = torch.from_numpy(img.reshape(-1)).cuda()
+        assert (_torch_checksum(d_in) == want["checksum"]).all(), "cannot reproduce the fixture's input image"
+    else:
+        img = d_in.cpu().numpy().reshape(H, W)
+    q = nq.PnnLABQuantizer(np.zeros((1, 1), np.int32), mode=TILED, seed=seed)
+    q.width, q.height = W, H
+    d_out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    d_idx = torch.zeros(W * H, dtype=torch.int16, device="cuda")
+    pal = q.convert_device(d_in.data_ptr(), 256, True, d_out.data_ptr(), d_idx.data_ptr())
+    torch.cuda.synchronize()
+    assert len(pal) == len(want["palette"]) and (pal == want["palette"]).all(), "%d palette entries differ from the oracle's" % int((pal != want["palette"]).sum())
+    p = q.params
+    assert [p.hasSemiTransparency, p.transparentPixelIndex, p.transparentColor, p.isNano, p.texicab, p.quan_rt, p.maxbins,
+            p.paletteLength] == list(want["scalars"])
+    assert (np.array([p.PR, p.PG, p.PB, p.PA, p.ratio, p.weight]) == want["doubles"]).all()
+    del d_in
+    # three tile rows against the oracle (it holds its own copy of the image; prescan sets PR..PA and the transparency fields)
+    oq = oracle.OracleQuantizer(1, img, seed=seed)
+    oq.prescan(256)
+    op = oq.params
+    for f, v in zip(("hasSemiTransparency", "transparentPixelIndex", "transparentColor", "isNano", "texicab", "quan_rt", "maxbins", "paletteLength"),
+                    want["scalars"].tolist()):
+        setattr(op, f, int(v))
+    op.nMaxColors = 256
+    op.PR, op.PG, op.PB, op.PA, op.ratio, op.weight = [float(v) for v in want["doubles"]]
+    op.distinctColors = int(want["distinct"])
+    oq.set_params(op)
+    oq.set_seed(seed)
+    for r in (0, 1027, 2047):
+        ys = slice(r * 8, r * 8 + 8)
+        want_argb, want_idx = oq.dither_tile_rows(pal, True, (8, 8), r, 1)
+        got_idx = d_idx[r * 8 * W:(r * 8 + 8) * W].cpu().numpy().view(np.uint16).reshape(8, W).astype(np.int32)
+        got_argb = d_out[r * 8 * W:(r * 8 + 8) * W].cpu().numpy().reshape(8, W)
+        assert (got_idx == want_idx[ys]).all(), "tile row %d: %d indices differ from the oracle" % (r, int((got_idx != want_idx[ys]).sum()))
+        assert (got_argb == want_argb[ys]).all()
+        del want_argb, want_idx

@@ -271,7 +271,11 @@ def test_tiled_output_within_the_stated_deltaE_tolerance_of_the_sequential_refer
     5 % + 0.1, p99.9 by more than 10 % + 0.5, the single worst pixel by more than 50 %), on the 8x8 local means between the two outputs (p99 <= 20 % of the sequential
     output's per-pixel p99, i.e. the patterns integrate to the same colours) and on the tile seams (mean Lab step across tile
     boundaries <= 1.05 x the step inside the tiles).  Measured (tests/tiled_vs_sequential.py): e.g. bench image p50/p99/max
-    1.15/3.72/6.79 tiled vs 1.15/3.71/6.93 sequential, local means p99 0.31, seam ratio 1.008."""
+    1.15/3.72/6.79 tiled vs 1.15/3.71/6.93 sequential, local means p99 0.31, seam ratio 1.008.
+    And directly BETWEEN the two outputs, pixel by pixel (CIE76 of tiled[i] against sequential[i]): p99 <= 1.5 x the sequential output's
+    p99 against the source + 0.5, worst pixel <= 2 x the sequential output's worst pixel against the source (two pixels that each sit
+    within e of the source could be 2 e apart; measured 1.0-1.4 x / 1.1-1.8 x: noise 256^2 p99 19.5 max 32.9 against 18.8 / 31.0,
+    bench image crop 6.9 / 15.7 against 5.0 / 10.4); 30-86 % of the pixels are identical.  The numbers are printed (pytest -s)."""
     img = mk()
     s = 9 if seed is None else seed
     H, W = img.shape
@@ -286,6 +290,11 @@ def test_tiled_output_within_the_stated_deltaE_tolerance_of_the_sequential_refer
     es, et = np.linalg.norm(ls - src, axis=2).ravel(), np.linalg.norm(lt - src, axis=2).ravel()
     ps, pt = [np.percentile(es, q) for q in (50, 99, 99.9, 100)], [np.percentile(et, q) for q in (50, 99, 99.9, 100)]
     assert pt[0] <= 1.05 * ps[0] + 0.1 and pt[1] <= 1.05 * ps[1] + 0.1 and pt[2] <= 1.10 * ps[2] + 0.5 and pt[3] <= 1.5 * ps[3], (name, ps, pt)
+    dts = np.linalg.norm(lt - ls, axis=2).ravel()
+    pd = [float(np.percentile(dts, q)) for q in (50, 99, 100)]
+    print("%s: deltaE76 tiled vs sequential per pixel p50/p99/max %.2f/%.2f/%.2f (identical pixels %.1f %%); sequential vs source p50/p99/p99.9/max "
+          "%.2f/%.2f/%.2f/%.2f; tiled vs source %.2f/%.2f/%.2f/%.2f" % ((name,) + tuple(pd) + (100.0 * float((got_argb == seq_argb).mean()),) + tuple(ps) + tuple(pt)))
+    assert pd[1] <= 1.5 * ps[1] + 0.5 and pd[2] <= 2.0 * ps[3], (name, pd, ps)
     db = np.linalg.norm(_box8(ls) - _box8(lt), axis=2).ravel()
     assert np.percentile(db, 99) <= 0.2 * ps[1] + 0.05, (name, float(np.percentile(db, 99)), ps)
     d = np.linalg.norm(np.diff(lt, axis=1), axis=2)

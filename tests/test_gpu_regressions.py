@@ -84,3 +84,33 @@ def test_one_handle_many_palettes(nq):
     for p in (p2, p1):
         one.set_params(params)
         assert (one.dither(p, True)[1] == fresh(p, True)).all()
+
+
+@pytest.mark.parametrize("kind,alpha,throws", [(0, 0xFF, False), (1, 0x80, False), (1, 0xFF, True)])
+def test_bin_count_saturates_at_two_to_the_24(nq, oracle, kind, alpha, throws):
+    """Pnnbin.cnt is a float, `cnt++` (RGB NQ/PnnQuantizer.java:153) / `cnt += 1` (LAB NQ/PnnLABQuantizer.java:154)
+    stops at 2^24 -- reachable from 4097^2 pixels up by any image with a flat region.  4200^2 = 17.64 M pixels, 17.61 M of them in one bin
+    (csrc/nq_palette.inc compact_means_kernel clamps the exact count; hist_segments_kernel runs that bin's float32 chains 17.6 M steps
+    long, the sums stalling where the float spacing exceeds the addend -- every rounding must fall as in the sequential sum).
+     * RGB, opaque: sums are exact doubles, means = sum / 2^24 (too large by 5 %), (int) alpha mean 268 -> Color.argb wraps;
+     * LAB, alpha 0x80 everywhere (4-4-4-4 keys): palette + scalars;
+     * LAB, opaque: the alpha mean is 256 -> ColorUtils.setAlphaComponent throws in the reference; the oracle reports it and the
+       GPU returns NQ_ERR_REFERENCE_THROWS."""
+    img = synth.flat_with_patch(4200, alpha, 77)
+    oq = oracle.OracleQuantizer(kind, img, seed=1)
+    oq.prescan(256)
+    gq = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(img, mode=nq.MODE_PARALLEL_TILED, seed=1)
+    if throws:
+        with pytest.raises(RuntimeError):
+            oq.pnnquan(256)
+        with pytest.raises(nq.NqError) as ei:
+            gq.pnnquan(256)
+        assert ei.value.status == -4                      # NQ_ERR_REFERENCE_THROWS
+        return
+    want = oq.pnnquan(256)
+    got = gq.pnnquan(256)
+    assert len(got) == len(want) and (got == want).all(), "%d palette entries differ" % int((got != want).sum())
+    po, pg = oq.params, gq.params
+    for f in ("hasSemiTransparency", "transparentPixelIndex", "isNano", "texicab", "quan_rt", "maxbins", "ratio", "weight"):
+        assert getattr(po, f) == getattr(pg, f), f
+    print("cnt saturation kind %d alpha %#x: maxbins %d, stage ms %s" % (kind, alpha, pg.maxbins, gq.stage_ms()))
