@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of BASELINE.json: Mpixels/s, 4096x4096 RGBA -> 256-colour PnnLAB + dither.
 
-One "step" = one batch (--batch, default 1024 = 64 GiB of input) of distinct 4096x4096 ARGB images, already resident in HBM, each through the
+One "step" = one batch (--batch, default 1536 = 96 GiB of input, 258 GiB with outputs and state: six merge loops per CU; shrunk to what
+the device's free memory holds) of distinct 4096x4096 ARGB images, already resident in HBM, each through the
 whole convert(256, dither=true): alpha pre-scan, histogram, find_nn, merge loop, palette fill, gilbert-curve error diffusion
 (PARALLEL_TILED).  The merge loop of one image is a sequential chain on one CU, so images are handed over in batches
-(nq_convert_batch_device): the merge loops of a batch run side by side, one workgroup each (four per CU at this batch size).
+(nq_convert_batch_device): the merge loops of a batch run side by side, one workgroup each (six per CU at this batch size).
 Device memory: batch x 160 MiB of pixel buffers (in, out, index) + 10 MiB of quantizer state per image.
 Multi-GPU (driver: torch.distributed.run, one rank per GPU): every rank converts its own batches (independent units,
 no data-path collective; RCCL only for the barrier / max-over-ranks of the time) -> "scaling": "weak".
@@ -118,8 +119,8 @@ def run_extras(nq, synth, slots, W, H, latency_ms, tile):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) * 1e3
 
-    # 1. smaller batches of the headline images (the headline needs ~1024 merge loops side by side)
-    out["batch_sweep"] = [batch_rate(slots[:n], 2) for n in (64, 256) if n <= len(slots)]
+    # 1. smaller batches of the headline images (the headline needs ~1500 merge loops side by side)
+    out["batch_sweep"] = [batch_rate(slots[:n], 2) for n in (64, 256, 1024) if n < len(slots)]
     # 2. BASELINE cfg 3 type (a): uniform random colours, every one of the 65 536 histogram bins occupied
     nu = min(4, len(slots))
     uni = [torch.from_numpy(synth.uniform_rgb(W, H, 3 + k).reshape(-1)).cuda() for k in range(nu)]
@@ -220,7 +221,7 @@ def main():
                     help="side of the CPU-baseline image (default: the headline's own 4096, ~80 s on one core; 0 = skip)")
     ap.add_argument("--no-dither", action="store_true", help="cfg5 only: convert(256, dither=false) -- the BlueNoise leg with the image-wide "
                                                              "distinct-colour count (presence-table all-reduce)")
-    ap.add_argument("--batch", type=int, default=1024,
+    ap.add_argument("--batch", type=int, default=1536,
                     help="images per step (distinct synthetic images, all resident in HBM): the merge loop of one image is a "
                          "sequential chain on one CU, a batch runs its merge loops side by side (nq_convert_batch_device)")
     ap.add_argument("--concurrency", type=int, default=1,

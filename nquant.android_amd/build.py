@@ -8,6 +8,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnquant_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# experiments: NQ_BUILD_TAG=x builds libnquant_hip.x.so from objects csrc/*.x.o with the extra defines NQ_BUILD_DEFS ("-DA=1 -DB"); the
+# host mirror loads it when NQ_LIB points at it (host.py library_path)
+TAG = os.environ.get("NQ_BUILD_TAG", "")
+if TAG:
+    LIB = os.path.join(HERE, "libnquant_hip.%s.so" % TAG)
+EXTRA_DEFS = os.environ.get("NQ_BUILD_DEFS", "").split()
 COMMON = (["-g"] if os.environ.get("NQ_BUILD_DEBUG") else []) + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 INC = os.path.join("..", "..", "include")
 # object -> (kind, sources it is rebuilt for)
@@ -19,13 +25,13 @@ UNITS = {
 }
 
 
-STAMP = os.path.join(CSRC, ".build_flags")
+STAMP = os.path.join(CSRC, ".build_flags" + ("." + TAG if TAG else ""))
 
 
 def _flags():
     """Everything outside the sources that changes the objects: the timing-experiment switches must never leak into a later normal build."""
-    return "debug=%s knockout=%s hipcc=%s common=%s" % (bool(os.environ.get("NQ_BUILD_DEBUG")), bool(os.environ.get("NQ_BUILD_KNOCKOUT")),
-                                                     HIPCC, " ".join(COMMON))
+    return "debug=%s knockout=%s hipcc=%s common=%s defs=%s" % (bool(os.environ.get("NQ_BUILD_DEBUG")), bool(os.environ.get("NQ_BUILD_KNOCKOUT")),
+                                                             HIPCC, " ".join(COMMON), " ".join(EXTRA_DEFS))
 
 
 def _newer(target, sources):
@@ -47,16 +53,16 @@ def build(force=False, verbose=False):
     if not same_flags:
         force = True
     for src, (kind, deps) in UNITS.items():
-        o = os.path.join(CSRC, src + ".o")
+        o = os.path.join(CSRC, src + (".%s.o" % TAG if TAG else ".o"))
         objs.append(o)
         if not force and not _newer(o, [os.path.join(CSRC, d) for d in deps] + [me]):
             continue
         if kind == "device":
-            cmd = [HIPCC, "--offload-arch=gfx950", "-x", "hip"] + COMMON + ["-c", os.path.join(CSRC, src), "-o", o]
+            cmd = [HIPCC, "--offload-arch=gfx950", "-x", "hip"] + COMMON + EXTRA_DEFS + ["-c", os.path.join(CSRC, src), "-o", o]
             if os.environ.get("NQ_BUILD_KNOCKOUT"):     # timing experiments (tools/knockout.sh): stages can be left out at run time
                 cmd.insert(-4, "-DNQ_FAST_KNOCKOUT")
         else:
-            cmd = [HIPCC, "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + COMMON + ["-c", os.path.join(CSRC, src), "-o", o]
+            cmd = [HIPCC, "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + COMMON + EXTRA_DEFS + ["-c", os.path.join(CSRC, src), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -509,6 +509,18 @@ __device__ __forceinline__ void ciede_terms_literal(const Lab& lab1, const Lab& 
     rt_out = R_T(barCPrime, barhPrime, deltaC, deltaH);
 }
 
+// ... out of line: the fast pass declines 0.2-3 % of the pairs, and the device library's pow / atan2 / sin / cos / exp inlined at every
+// call site of the exact evaluation (~1500 instructions each, with their own register appetite) were most of the merge kernel's code
+struct CiedeTerms { float dL, dC, dH, rt; };
+__device__ __attribute__((noinline)) CiedeTerms ciede_terms_literal_ool(float L1, float A1, float B1, float L2, float A2, float B2) {
+    Lab a, b;
+    a.alpha = 255.f; a.L = L1; a.A = A1; a.B = B1;
+    b.alpha = 255.f; b.L = L2; b.A = A2; b.B = B2;
+    CiedeTerms t;
+    ciede_terms_literal(a, b, t.dL, t.dC, t.dH, t.rt);
+    return t;
+}
+
 // :215-227 / :229-238
 __device__ __forceinline__ double color2Y(int c) {
     double sr = g_tab.gamma[c_red(c)], sg = g_tab.gamma[c_green(c)], sb = g_tab.gamma[c_blue(c)];

@@ -257,13 +257,14 @@ static hipError_t launch_merge_variant(K kernel, size_t dyn, int threads, const 
 // XCDs of the device: workgroups are dealt out to them round-robin by blockIdx, so a team whose members share blockIdx % NQ_XCDS shares
 // an L2.  There is no HIP attribute for it (gfx950: 8); a different count only costs the teams their shared L2, never a result.
 #define NQ_XCDS 8
+// 512 / 256 / 128 threads, or 127 = the dense 128-thread variant (six workgroups per CU: more than four loops per CU in flight)
 static int merge_threads_for(int n_in_flight, int n_cus) {
-    if (const char* f = std::getenv("NQ_MERGE_THREADS")) {       // tests: force one variant (512, 256 or 128)
+    if (const char* f = std::getenv("NQ_MERGE_THREADS")) {       // tests: force one variant (512, 256, 128 or 127)
         const int t = std::atoi(f);
-        if (t == 128 || t == 256 || t == 512) return t;
+        if (t == 127 || t == 128 || t == 256 || t == 512) return t;
     }
     if (n_cus < 1) n_cus = 1;
-    return n_in_flight <= n_cus ? 512 : n_in_flight <= 2 * n_cus ? 256 : 128;
+    return n_in_flight <= n_cus ? 512 : n_in_flight <= 2 * n_cus ? 256 : n_in_flight <= 4 * n_cus ? 128 : 127;
 }
 int merge_team_helpers(int n_jobs, int n_in_flight, int n_cus) {
     if (n_jobs <= 0 || merge_threads_for(n_in_flight, n_cus) != 512) return 0;
@@ -289,11 +290,20 @@ hipError_t launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight
         if (kind == 1) return launch_merge_variant(m512::merge_kernel<1>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
         return launch_merge_variant(m512::merge_kernel<0>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
     }
+    // the batch variants carry no phase stamps (nq_merge.inc, STATS); NQ_MERGE_STATS=1 selects the stamped 128-thread LAB build (diagnostics)
     if (threads == 256) {
-        if (kind == 1) return launch_merge_variant(m256::merge_kernel<1>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
-        return launch_merge_variant(m256::merge_kernel<0>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
+        if (kind == 1) return launch_merge_variant(m256::merge_kernel<1, false, false>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
+        return launch_merge_variant(m256::merge_kernel<0, false, false>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
     }
-    if (kind == 1) return launch_merge_variant(m128::merge_kernel<1>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
-    return launch_merge_variant(m128::merge_kernel<0>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
+    if (threads == 127) {
+        if (kind == 1) return launch_merge_variant(m128d::merge_kernel<1, false, false>, sizeof(m128d::MergeLds), 128, d_jobs, n, s);
+        return launch_merge_variant(m128d::merge_kernel<0, false, false>, sizeof(m128d::MergeLds), 128, d_jobs, n, s);
+    }
+    if (kind == 1) {
+        const char* f = std::getenv("NQ_MERGE_STATS");
+        if (f && std::atoi(f) == 1) return launch_merge_variant(m128::merge_kernel<1, false, true>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
+        return launch_merge_variant(m128::merge_kernel<1, false, false>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
+    }
+    return launch_merge_variant(m128::merge_kernel<0, false, false>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
 }
 } // namespace nq

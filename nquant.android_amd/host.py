@@ -51,7 +51,8 @@ class Params(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libnquant_hip.so")
+    """libnquant_hip.so next to this file; NQ_LIB=<path> loads another build of it (kernel experiments: build.py NQ_BUILD_TAG)."""
+    return os.environ.get("NQ_LIB") or os.path.join(_HERE, "libnquant_hip.so")
 
 
 def _preload_hip_runtime():

@@ -49,7 +49,7 @@ def test_oracle_reproduces_golden_palette(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("threads", [512, 256, 128])
+@pytest.mark.parametrize("threads", [512, 256, 128, 127])      # 127 = the dense 128-thread variant (six workgroups per CU)
 @pytest.mark.parametrize("name", sorted(mg.PALETTE_CASES))
 def test_gpu_reproduces_golden_palette_every_merge_variant(nq, name, threads, monkeypatch):
     """~64k bins: beyond the LDS mirrors of every merge-workgroup variant (csrc/nq_merge.inc), all 1005 position blocks in use."""

@@ -6,6 +6,10 @@ import nquant.android_amd as nq
 from nquant.android_amd import synth
 B = int(sys.argv[1]); kind = int(sys.argv[2]); W = H = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 cls = nq.PnnLABQuantizer if kind else nq.PnnQuantizer
+free_b, total_b = torch.cuda.mem_get_info()
+print("device memory: free %.1f GiB of %.1f GiB; batch needs %.1f GiB" % (free_b / 2**30, total_b / 2**30, B * (10 * W * H + (12 << 20)) / 2**30), flush=True)
+if B * (10 * W * H + (12 << 20)) + (8 << 30) > free_b:
+    raise SystemExit("batch does not fit")
 qs, ins, outs = [], [], []
 for b in range(B):
     q = cls(np.zeros((1, 1), np.int32), mode=1, seed=3 + b)
@@ -28,6 +32,8 @@ print("image 0 team: helpers %d published %d used %d timeouts %d wait %.2f us pe
 tss = [q.team_stats() for q in qs]
 print("loops that gave up on their helpers at least once: %d of %d (%d times in all); without them at the end: %d" % (
     sum(1 for t in tss if t["gave_up"]), B, sum(t["gave_up"] for t in tss), sum(1 for t in tss if t["helpers"] > 0 and not t["speculating_at_end"])))
+if not st["find_ticks_100MHz"]:
+    print("(the batch variants of the merge kernel carry no phase stamps: NQ_MERGE_STATS=1 selects the stamped 128-thread build)")
 busy = sorted((q.merge_stats()["find_ticks_100MHz"] + q.merge_stats()["ctrl_ticks_100MHz"]) / 1e5 for q in qs)
 print("loop busy time (find + control) ms: min %.0f median %.0f p99 %.0f max %.0f | batch phases %s" % (busy[0], busy[len(busy) // 2], busy[int(len(busy) * 0.99)], busy[-1], qs[0].batch_phase_ms()))
 print("image 0 control ms: total %.1f | sifts %.1f (pops %d) merges %.1f top fetch %.1f find epilogues %.1f (incl. their sift)" % (
