@@ -46,6 +46,12 @@ struct FastArgs {
     const uint4* cont;       // [2][65536]: candidates 15..30 of the closest / nearest lists
     int debug;               // timing experiments only (builds with -DNQ_FAST_KNOCKOUT): bit mask of stages to leave out
 };
+// instruction budget by block (tools/fast_budget.py compiles this file with -DNQ_FAST_MARKS and counts between the markers)
+#ifdef NQ_FAST_MARKS
+#define NQ_MARK(name) asm volatile("; MARK " name)
+#else
+#define NQ_MARK(name)
+#endif
 #ifdef NQ_FAST_KNOCKOUT
 #define NQ_KO(bit) (F.debug & (bit))
 #else
@@ -554,6 +560,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                 if (hasSal) sal_next = saliency[bidx_next];
             }
 
+            NQ_MARK("step_begin");
             float e[4] = {(float) c_red(pixel), (float) c_green(pixel), (float) c_blue(pixel), (float) c_alpha(pixel)};
             float maxErr = 24.0f;               // DITHER_MAX - 1
             if (!NQ_KO(32))
@@ -569,10 +576,12 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
             const int b_pix = (int) fminf(255.0f, fmaxf(e[2], 0.0f));
             const int a_pix = (int) fminf(255.0f, fmaxf(e[3], 0.0f));
             const int c2 = c_argb(a_pix, r_pix, g_pix, b_pix);
+            NQ_MARK("accumulated");
 
             // :212-229 (K > 32: never branch B)
             int c = c2;
             if (branchA && !(K >= 256 && sal > .99f) && !NQ_KO(8)) c = fast_dither_color(S, G, K, xx, yy, c2, pixel, sal);
+            NQ_MARK("dither_color");
 
             // ---- Ditherable.nearestColorIndex(palette, c, bidx) = closestColorIndex (K > 4), NQ/PnnLABQuantizer.java:407-474
             int qidx = 0;
@@ -594,13 +603,17 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                 const int ncl = (int) (la.w >> 24), nnr = (int) (na.w >> 24);
                 if (ncl == 255 || nnr == 255) failed = true;
                 const int n1 = (ncl == 255 || NQ_KO(16)) ? 0 : ncl, n2 = nnr == 255 ? 0 : nnr;
+                NQ_MARK("lists_fetched");
                 const FastClosest t = fast_closest_tuple(S, X, c, la, n1, cell);
+                NQ_MARK("closest_done");
                 const int idx = fast_closest_pick(t, rng);              // :465-468
                 const int ci = idx ? t.c1 : t.c0, ei = idx ? t.e1 : t.e0;
                 qidx = ci;
+                NQ_MARK("picked");
                 if ((ei >= K || ci == 0 || c_alpha(S.argb[ci]) < c_alpha(c)) && !NQ_KO(2)) {
                     qidx = fast_nearest(S, X, c, na, n2, cell);
                 }
+                NQ_MARK("nearest_done");
             }
 
             // :236-264
@@ -610,6 +623,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
             e[2] = (float) (b_pix - c_blue(cq));
             e[3] = (float) (a_pix - c_alpha(cq));
             const bool diffuse = S.blue[(bidx + gofs) & 4095] > G.thresold;
+            NQ_MARK("error_formed");
             {
                 float ea = e[0], eb = e[1], ec = e[2];
 #pragma unroll 1
@@ -623,6 +637,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                 }
                 e[0] = ea; e[1] = eb; e[2] = ec;
             }
+            NQ_MARK("limited");
             // errorq.poll() + errorq.add(error): box 25 + u of the window; after the fifth step the window moves down by five
             switch (u) {
                 case 0: q[25][0] = e[0]; q[25][1] = e[1]; q[25][2] = e[2]; q[25][3] = e[3]; asm volatile("; push 0"); break;
@@ -644,6 +659,7 @@ __global__ void __launch_bounds__(256, MINWAVES) gilbert_fast_kernel(DevParams P
                     break;
             }
             stage[pos] = (unsigned char) qidx;
+            NQ_MARK("step_end");
         }
     }
 

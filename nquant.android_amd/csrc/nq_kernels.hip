@@ -101,6 +101,20 @@ static void launch_gilbert_t(const DevParams& P, const GilbertConsts& G, const T
     const size_t base = palette_tables_smem_bytes(P.kind, P.K);
     const int tilepx = T.tile_w * T.tile_h;
     const bool stage = P.K <= 256 && tilepx <= 256 && !sequential;
+    const size_t front = (base + (stage ? (size_t) 64 * tilepx : 0) + 15) & ~(size_t) 15;
+    // sorted-by-yDiff queue: in LDS (48 KB per workgroup) whenever it fits next to the staged palette, else per-lane arrays in scratch
+    if (SORTED && front + NQ_QLDS_BYTES <= 160 * 1024 - 1024) {
+        if (stage) {
+            allow_big_lds(gilbert_kernel<SORTED, DM, true, SORTED>, front + NQ_QLDS_BYTES);
+            hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, true, SORTED>), dim3(grid), dim3(block), front + NQ_QLDS_BYTES, s, P, G, T, L, d_pixels,
+                               d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, d_tile_list);
+        } else {
+            allow_big_lds(gilbert_kernel<SORTED, DM, false, SORTED>, front + NQ_QLDS_BYTES);
+            hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, false, SORTED>), dim3(grid), dim3(block), front + NQ_QLDS_BYTES, s, P, G, T, L, d_pixels,
+                               d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, d_tile_list);
+        }
+        return;
+    }
     allow_big_lds(gilbert_kernel<SORTED, DM, false>, base);
     if (stage)
         hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, true>), dim3(grid), dim3(block), base + (size_t) 64 * tilepx, s, P, G, T, L, d_pixels,

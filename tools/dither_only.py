@@ -24,7 +24,11 @@ q.set_tile(tile, tile)
 q.set_option(host.OPT_FAST_DITHER, fast)
 d_out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
 d_idx = torch.zeros(W * H, dtype=torch.int16, device="cuda")
+acc = []
 for it in range(reps):
     q.dither_device(d_in.data_ptr(), pal, bool(dither), d_out.data_ptr(), d_idx.data_ptr(), mode=mode)
-torch.cuda.synchronize()
-print("done", q.dither_path())
+    torch.cuda.synchronize()
+    acc.append(q.stage_ms()["dither"])
+import hashlib
+print("done", q.dither_path(), "dither stage ms: min %.4f median %.4f" % (min(acc), sorted(acc)[len(acc) // 2]),
+      "index sha", hashlib.sha256(d_idx.cpu().numpy().tobytes()).hexdigest()[:16], "NQ_FAST_NO_OPAQUE" in os.environ)
