@@ -349,6 +349,11 @@ def main():
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t0) * 1e3
     single_stages = q0.stage_ms()
+    # the same convert once more with the STAMPED build of the merge kernel (NQ_MERGE_STATS=1: phase ticks for "merge_stats"; ~4 % slower, untimed)
+    os.environ["NQ_MERGE_STATS"] = "1"
+    q0.convert_device(slots[0]["in"].data_ptr(), 256, True, slots[0]["out"].data_ptr(), slots[0]["idx"].data_ptr())
+    torch.cuda.synchronize()
+    del os.environ["NQ_MERGE_STATS"]
     single_merge_stats = q0.merge_stats()
     run_all(args.warmup, False)
 
@@ -419,6 +424,7 @@ def main():
                                    % (W, H, args.workload, tile, tile, Bn),
                        "palette": int(len(pals[0])), "maxbins": int(p.maxbins),
                        "parallelism": "independent images per GPU, no collective",
+                       "collective_backend": (backend if world > 1 else None),
                        "batch": Bn, "concurrency": T, "images_per_s": round(world * images / dt, 2),
                        "ms_per_image": round(dt / images * 1e3, 3),
                        "single_convert_latency_ms": round(latency_ms, 2)},
@@ -518,6 +524,7 @@ def bench_cfg4(args, nq, synth, dist, rank, local_rank, world):
             "config": {"workload": "BASELINE cfg 4: 64 frames of 1920x1080 ARGB_8888 gradient_noise (seeds 100 + f), PnnLABQuantizer.convert(256, "
                                    "dither=true), PARALLEL_TILED automatic tiles (4x4); frame f on rank f mod N, one nq_convert_batch_device call per rank and step",
                        "frames": frames, "frames_per_rank": len(slots), "parallelism": "independent frames per GPU, no collective",
+                       "collective_backend": (os.environ.get("NQ_BENCH_BACKEND", "nccl") if world > 1 else None),
                        "frames_per_s": round(args.steps * frames / dt, 2)},
             "roofline": {"bound": "hbm", "kernel": "gilbert_fast_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * npx,
@@ -568,15 +575,17 @@ def bench_cfg5(args, nq, synth, dist, rank, local_rank, world):
         achieved = BYTES_PER_PIXEL * band_px / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         hist_bytes = 65536 * 5 * 8
         emit(({
-            "metric": "Mpixels/sec, 16384x16384 RGBA tiled across the GPUs -> 256-colour PnnLAB%s (RCCL histogram exchange)"
-                      % (", dither=false + BlueNoise post-pass" if args.no_dither else " + dither"),
+            "metric": "Mpixels/sec, 16384x16384 RGBA tiled across the GPUs -> 256-colour PnnLAB%s (%s histogram exchange)"
+                      % (", dither=false + BlueNoise post-pass" if args.no_dither else " + dither",
+                         "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " [REHEARSAL backend, not RCCL]"),
             "value": round(args.steps * W * H / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE cfg 5: one 16384x16384 ARGB_8888 gradient_noise image (seed 5) in %d row bands of <= %d rows; per step: band "
                                    "pre-scan -> all-gather of 3 int64 -> band histogram -> all-gather of the 2.6 MB f64 partials -> palette on every rank "
                                    "(merge loop replicated) -> dither of the band with global tile indices" % (world, rows),
-                       "parallelism": "row bands, one exchange step (RCCL all-gather), merge loop replicated", "palette": int(len(pal))},
+                       "parallelism": "row bands, one exchange step (all-gather), merge loop replicated", "collective_backend": dist.get_backend(),
+                       "palette": int(len(pal))},
             "collectives": {"per_step_bytes_received_per_rank": world * (hist_bytes + 24), "histogram_partial_bytes": hist_bytes,
                             "seconds_per_step_in_collectives": round(timings.get("collectives", 0.0) / args.steps, 6),
                             "seconds_per_step_palette_build": round(timings.get("palette", 0.0) / args.steps, 6),

@@ -295,16 +295,23 @@ int merge_team_helpers(int n_jobs, int n_in_flight, int n_cus) {
 hipError_t launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight, int n_cus, int helpers, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int threads = merge_threads_for(n_in_flight, n_cus);
+    // Phase stamps (nq_merge.inc, STATS) cost ~20 scalar-cache round trips per find_nn event: every variant runs without them unless
+    // NQ_MERGE_STATS=1 asks for the stamped build (tools/latency.py, tools/batch_rate.py: the tick fields of nq_get_merge_stats /
+    // nq_get_team_stats are 0 otherwise; the event counters are always there)
+    const char* fs = std::getenv("NQ_MERGE_STATS");
+    const bool stats = fs && std::atoi(fs) == 1;
     if (threads == 512) {
         if (helpers > 0) {
             const int n_pad = (n + NQ_XCDS - 1) / NQ_XCDS * NQ_XCDS;
-            if (kind == 1) return launch_merge_variant(m512::merge_kernel<1, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
-            return launch_merge_variant(m512::merge_kernel<0, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
+            if (kind == 1) return stats ? launch_merge_variant(m512::merge_kernel<1, true, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers)
+                                        : launch_merge_variant(m512::merge_kernel<1, true, false>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
+            return stats ? launch_merge_variant(m512::merge_kernel<0, true, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers)
+                         : launch_merge_variant(m512::merge_kernel<0, true, false>, sizeof(m512::MergeLds), 512, d_jobs, n, s, n_pad, 1 + helpers);
         }
-        if (kind == 1) return launch_merge_variant(m512::merge_kernel<1>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
-        return launch_merge_variant(m512::merge_kernel<0>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
+        if (kind == 1) return stats ? launch_merge_variant(m512::merge_kernel<1, false, true>, sizeof(m512::MergeLds), 512, d_jobs, n, s)
+                                    : launch_merge_variant(m512::merge_kernel<1, false, false>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
+        return launch_merge_variant(m512::merge_kernel<0, false, false>, sizeof(m512::MergeLds), 512, d_jobs, n, s);
     }
-    // the batch variants carry no phase stamps (nq_merge.inc, STATS); NQ_MERGE_STATS=1 selects the stamped 128-thread LAB build (diagnostics)
     if (threads == 256) {
         if (kind == 1) return launch_merge_variant(m256::merge_kernel<1, false, false>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
         return launch_merge_variant(m256::merge_kernel<0, false, false>, sizeof(m256::MergeLds), 256, d_jobs, n, s);
@@ -314,8 +321,7 @@ hipError_t launch_merge(int kind, const MergeJob* d_jobs, int n, int n_in_flight
         return launch_merge_variant(m128d::merge_kernel<0, false, false>, sizeof(m128d::MergeLds), 128, d_jobs, n, s);
     }
     if (kind == 1) {
-        const char* f = std::getenv("NQ_MERGE_STATS");
-        if (f && std::atoi(f) == 1) return launch_merge_variant(m128::merge_kernel<1, false, true>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
+        if (stats) return launch_merge_variant(m128::merge_kernel<1, false, true>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
         return launch_merge_variant(m128::merge_kernel<1, false, false>, sizeof(m128::MergeLds), 128, d_jobs, n, s);
     }
     return launch_merge_variant(m128::merge_kernel<0, false, false>, sizeof(m128::MergeLds), 128, d_jobs, n, s);

@@ -1,7 +1,8 @@
 """Single-convert latency and merge-loop counters on the bench image (4096^2 gradient+noise, LAB, 256 colours).
 python tools/latency.py [side] [kind 0|1] [uniform]"""
 import sys, time
-import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import os; os.environ.setdefault("NQ_MERGE_STATS", "1")          # the stamped merge kernel: the per-phase ticks below need it (~4 % slower)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 import nquant.android_amd as nq
 from nquant.android_amd import synth
