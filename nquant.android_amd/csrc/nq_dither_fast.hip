@@ -813,69 +813,6 @@ __global__ void __launch_bounds__(256) fast_lookup_pass1_kernel(DevParams P, Fas
         }
     }
 }
-// Pass 1, four pixels per lane (round 4).  The one-pixel form is a chain of three dependent memory latencies per iteration (pixel ->
-// list record of its cell -> palette Lab from LDS) with ONE of each in flight per lane: PMC had the wavefronts waiting 77 % of their
-// cycles at 8 per SIMD, VALU issue at 50 %.  Here a lane loads four consecutive pixels with one 16-byte access, requests their four list
-// records back to back, evaluates them one after the other and stores the four indices / colours with one 8-byte / 16-byte access.
-// Same functions on the same values: identical results (the deferred list may hold the same pixels in another order).
-// Needs N % 4 == 0 and 16-byte aligned pixels / out_argb, 8-byte aligned out_index (launch_fast_lookup_only checks).
-__global__ void __launch_bounds__(256) fast_lookup_pass1_vec4_kernel(DevParams P, FastArgs F, const int* __restrict__ g_palette,
-                                                                     const int4* __restrict__ pixels4, long long N4,
-                                                                     uint2* __restrict__ out_index4, int4* __restrict__ out_argb4,
-                                                                     unsigned* __restrict__ todo /* [0] = count, [1..] = pixel indices */) {
-    __shared__ __align__(16) int s_argb[256];
-    __shared__ __align__(16) float4 s_lab[256];
-    __shared__ float s_gamma32[256];
-    const int tid = threadIdx.x;
-    {
-        const int c2 = tid < P.K ? g_palette[tid] : 0;
-        s_argb[tid] = c2;
-        const Lab l2 = RGB2LAB(c2);
-        s_lab[tid] = make_float4(l2.L, l2.A, l2.B, 0.f);
-        s_gamma32[tid] = (float) g_tab.gamma[tid];
-    }
-    __syncthreads();
-    FastLds S;
-    S.argb = s_argb; S.lab = s_lab; S.gamma = nullptr; S.gamma32 = s_gamma32; S.blue = nullptr; S.path = nullptr; S.tileinfo = nullptr; S.stage = nullptr;
-    FastLookup X;
-    X.packed = F.packed; X.cont = F.cont; X.qa = X.qb = X.qc = 0.f; X.wr = X.wg = X.wb = X.ratio = 0.0;
-    X.kfirst = P.hasAlpha ? 1 : 0;
-    const int lane = tid & 63;
-    const long long stride = (long long) gridDim.x * blockDim.x;
-    const long long n_round = (N4 + stride - 1) / stride * stride;             // whole wavefronts stay in the loop (ballots below)
-    for (long long g = (long long) blockIdx.x * blockDim.x + tid; g < n_round; g += stride) {
-        const bool in = g < N4;
-        int4 v = make_int4((int) 0xFF000000, (int) 0xFF000000, (int) 0xFF000000, (int) 0xFF000000);
-        if (in) v = pixels4[g];
-        const int c[4] = {v.x, v.y, v.z, v.w};
-        int cell[4]; uint4 na[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { cell[j] = cell_of(c[j]); na[j] = X.packed[2 * cell[j] + 1]; }       // four gathers in flight
-        int k[4]; bool safe[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            k[j] = 0; safe[j] = false;
-            const int n = (int) (na[j].w >> 24);
-            if (c_alpha(c[j]) > 0xF && n != 255) k[j] = fast_nearest32(S, X, c[j], na[j], n, cell[j], safe[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool defer = in && !safe[j];
-            const unsigned long long dm = __ballot(defer);
-            if (dm) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(&todo[0], (unsigned) __popcll(dm));
-                base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
-                if (defer) todo[1 + base + __popcll(dm & ((1ULL << lane) - 1ULL))] = (unsigned) (4 * g + j);
-            }
-        }
-        if (in) {
-            // (a deferred pixel's slot holds index 0 / palette[0] until pass 2 overwrites it: pass 2 runs behind this kernel on the stream)
-            if (out_index4) { uint2 iv; iv.x = (unsigned) k[0] | ((unsigned) k[1] << 16); iv.y = (unsigned) k[2] | ((unsigned) k[3] << 16); out_index4[g] = iv; }
-            if (out_argb4) out_argb4[g] = make_int4(s_argb[k[0]], s_argb[k[1]], s_argb[k[2]], s_argb[k[3]]);
-        }
-    }
-}
 __global__ void __launch_bounds__(256) fast_lookup_pass2_kernel(DevParams P, CellLists lists, FastArgs F, const int* __restrict__ g_palette,
                                                                 const int* __restrict__ pixels, unsigned short* __restrict__ out_index,
                                                                 int* __restrict__ out_argb, const unsigned* __restrict__ todo) {
@@ -1065,15 +1002,6 @@ void launch_fast_lookup_only(const DevParams& P, const ListsView& lv, const int*
     int64_t g1 = (N + 255) / 256;
     if (g1 > 256 * 32) g1 = 256 * 32;                // 32 workgroups per CU in flight: 8 wavefronts per SIMD, four passes over them
     if (g1 < 1) g1 = 1;
-    const bool vec4 = (N % 4) == 0 && ((uintptr_t) d_pixels % 16) == 0 && ((uintptr_t) d_argb % 16) == 0 && ((uintptr_t) d_index % 8) == 0 &&
-                      std::getenv("NQ_LOOKUP_SCALAR") == nullptr;                  // (NQ_LOOKUP_SCALAR: tests / measurements of the one-pixel form)
-    if (vec4) {
-        int64_t g4 = (N / 4 + 255) / 256;
-        if (g4 > 256 * 16) g4 = 256 * 16;
-        if (g4 < 1) g4 = 1;
-        hipLaunchKernelGGL(fast_lookup_pass1_vec4_kernel, dim3((unsigned) g4), dim3(256), 0, s, P, F, d_palette, (const int4*) d_pixels, (long long) (N / 4),
-                           (uint2*) d_index, (int4*) d_argb, d_todo);
-    } else
     hipLaunchKernelGGL(fast_lookup_pass1_kernel, dim3((unsigned) g1), dim3(256), 0, s, P, F, d_palette, d_pixels, (long long) N, d_index, d_argb, d_todo);
     hipLaunchKernelGGL(fast_lookup_pass2_kernel, dim3(1024), dim3(256), 0, s, P, to_lists_fast(lv), F, d_palette, d_pixels, d_index, d_argb,
                        (const unsigned*) d_todo);
