@@ -22,7 +22,7 @@ Prints ONE JSON line on rank 0 (contract in the round prompt) with extra objects
   batch_sweep, cfg3a_uniform, photo, host_batch, single_image_mpixels_s -- N = 1 only, after the timed region (--no-extras skips them):
                     smaller batches of the same images; BASELINE cfg 3 type (a) (uniform random colours, 65 536 bins: the worst case for
                     pnnquan) as single-image latency and a batch of 256; the reference's own sample photograph tiled to 4096^2 (a photographic
-                    histogram: 2970 bins, sorted-by-yDiff queue, 64x64 tiles, generic dither kernel); the PCIe-inclusive rate of
+                    histogram: 2970 bins, sorted-by-yDiff queue, generic dither kernel); the PCIe-inclusive rate of
                     nq_convert_batch over page-locked host buffers (never the headline `value`);
   amortised_ms_per_image -- the three phases of a batch call (HIP events on the launch stream) divided by the batch size;
   cpu_baseline   -- the CPU oracle (C restatement of the reference's sequential Java path, 1 core) on the SAME 4096x4096 image
@@ -138,7 +138,7 @@ def run_extras(nq, synth, slots, W, H, latency_ms, tile):
         nph = min(64, len(slots))
         pho = [torch.from_numpy(photo_image(W, H, k).reshape(-1)).cuda() for k in range(min(7, nph))]
         for s in slots[:nph]:
-            s["q"].set_tile(0, 0)            # automatic: 64x64 for the sorted-by-yDiff queue this histogram selects
+            s["q"].set_tile(0, 0)            # the library's automatic rule
         lat = single(slots[0]["q"], pho[0], slots[0])
         st = slots[0]["q"].stage_ms()
         fast = slots[0]["q"].dither_path()[0]

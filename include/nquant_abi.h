@@ -87,8 +87,8 @@ int nq_abi_version(void);
 /* All work of the handle is enqueued on this hipStream_t (NULL = the default stream). */
 int nq_set_stream(nq_handle* h, void* hip_stream);
 /* Tile of the PARALLEL_TILED decomposition; <= 0 (default) = automatic: 8x8 when that gives the GPU at least 131072
- * independent chains (images from about 2900^2 pixels), 4x4 below that; 64x64 when the GilbertCurve constructor selects the sorted-by-yDiff
- * queue (K > 128 && weight >= .02: its start-up transient at every chain start costs quality with short chains). */
+ * independent chains (images from about 2900^2 pixels), 4x4 below that -- for every form of the error queue (a tile chain of the
+ * sorted-by-yDiff mode, K > 128 && weight >= .02, starts with its queue in the steady state instead of re-growing it per tile). */
 int nq_set_tile(nq_handle* h, int tile_w, int tile_h);
 /* One image tiled over GPUs: this handle's following nq_dither[_device] calls treat their pixel buffer as the rows
  * [y0, y0 + height) of an image of image_height rows -- tile random streams, the blue-noise phase and the position-dependent

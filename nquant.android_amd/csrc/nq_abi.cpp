@@ -776,11 +776,7 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
             const int64_t tiles = (int64_t) ((width + cand - 1) / cand) * ((rule_h + cand - 1) / cand);
             if (tiles >= 131072) tsz = cand;
         }
-        // sorted-by-yDiff queue (few-bin images: K > 128 && weight >= .02): the queue GROWS 1 -> 3 -> 7 -> 15 from empty at the start
-        // of every chain (NQ/GilbertCurve.java:231-234) and the first pixels of a chain occasionally land far off (measured with the
-        // oracle, 192^2 / 2000 bins: 56 pixels with deltaE > 40 against the source with 4x4 tiles, 14 with 8x8, 0 with 64x64, 0 in
-        // the sequential reference) -- chains are kept long there: quality first, such images are small or flat anyway
-        if (G.sortedByYDiff) tsz = 64;
+        // (the sorted-by-yDiff queue takes the same rule since round 4: its tile chains start in the queue's steady state, nq_dither.inc)
         T.tile_w = std::min(tsz, width); T.tile_h = std::min(tsz, rule_h);
     }
     if (banded) {

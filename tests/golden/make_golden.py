@@ -50,14 +50,14 @@ LOOKUP_CASES = {
 # activity quantizes with `new PnnQuantizer(path).convert(256, true)` (app/src/main/java/nQuant/android/MainActivity.java:190-194) and
 # the README's `new PnnLABQuantizer(path).convert(256, true)`.  A photographic histogram: 2970 bins -> weight 0.086 (colour-keyed
 # caches, not isNano), quan_rt 1, GilbertCurve sorted-by-yDiff queue with DITHER_MAX 9 -- rungs no synthetic generator reaches at K = 256.
-# Per case: palette + scalars, the whole convert in REFERENCE_SEQUENTIAL mode, and the tiled decomposition (64x64 tiles: the automatic
-# rule for the sorted queue).
+# Per case: palette + scalars, the whole convert in REFERENCE_SEQUENTIAL mode, and the tiled decomposition (8x8 tiles, ragged at the right
+# and bottom edges of the 495 x 438 picture; the chains of the sorted queue start in its steady state, oracle: gilbert_run).
 def sample_image():
     rgb = np.load(os.path.join(OUT, "sample_495x438.npz"))["rgb"].astype(np.uint32)
     return ((np.uint32(255) << np.uint32(24)) | (rgb[..., 0] << np.uint32(16)) | (rgb[..., 1] << np.uint32(8)) | rgb[..., 2]).view(np.int32)
 
 
-SAMPLE_TILE = (64, 64)
+SAMPLE_TILE = (8, 8)
 SAMPLE_CASES = {
     "sample_rgb256_dither": dict(kind=0, K=256, dither=True, seed=7),
     "sample_lab256_dither": dict(kind=1, K=256, dither=True, seed=7),

@@ -150,10 +150,10 @@ def test_gpu_sample_photo_whole_convert_sequential(nq, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(mg.SAMPLE_CASES))
-def test_gpu_sample_photo_tiled(nq, name):
-    """The same calls in the production mode (PARALLEL_TILED): 64x64 tiles, ragged at the right and bottom edges (495 x 438), against
-    the oracle's tiled restatement held by the fixture; for the 256-colour cases (sorted-by-yDiff queue) the automatic tile rule must
-    choose exactly this decomposition."""
+def test_gpu_sample_photo_tiled(nq, oracle, name):
+    """The same calls in the production mode (PARALLEL_TILED): 8x8 tiles, ragged at the right and bottom edges (495 x 438), against
+    the oracle's tiled restatement held by the fixture (256 colours: the sorted-by-yDiff queue, whose tile chains start in the queue's
+    steady state); and the AUTOMATIC tile rule (4x4 at this size, for every queue form) against the oracle run here."""
     c = mg.SAMPLE_CASES[name]
     want = np.load(os.path.join(HERE, "golden", name + ".npz"))
     q = _sample_quantizer(nq, c, nq.MODE_PARALLEL_TILED, tile=mg.SAMPLE_TILE)
@@ -162,7 +162,12 @@ def test_gpu_sample_photo_tiled(nq, name):
     nbad = int((out.index != want["tiled_index"]).sum())
     assert nbad == 0, "%d of %d indices differ" % (nbad, out.index.size)
     assert (mg._sha(out.argb) == want["tiled_argb_sha256"]).all()
-    if c["K"] > 128:
-        q2 = _sample_quantizer(nq, c, nq.MODE_PARALLEL_TILED)
-        out2 = q2.convert(c["K"], c["dither"])
-        assert (out2.index == out.index).all() and (out2.argb == out.argb).all()
+    img = mg.sample_image()
+    oq = oracle.OracleQuantizer(c["kind"], img, seed=c["seed"])
+    oq.prescan(c["K"])
+    pal = oq.pnnquan(c["K"])
+    oq.set_seed(c["seed"])
+    want_argb, want_idx = oq.dither(pal, c["dither"], tile=(4, 4))
+    q2 = _sample_quantizer(nq, c, nq.MODE_PARALLEL_TILED)
+    out2 = q2.convert(c["K"], c["dither"])
+    assert (out2.index.astype(np.int32) == want_idx).all() and (out2.argb == want_argb).all()

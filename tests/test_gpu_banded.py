@@ -118,10 +118,7 @@ def test_bands_by_hand_equal_oracle_banded(nq, oracle, kind, K, dither, mk, star
     want_pal = oq.pnnquan(K)
     otile = tile
     if otile is None:
-        otile = (4, 4)          # automatic rule at this size ...
-        op = oq.params
-        if len(want_pal) > 128 and op.weight >= .02 and not op.hasSemiTransparency:
-            otile = (min(64, W), min(64, H))         # ... unless the constructor selects the sorted-by-yDiff queue: 64x64
+        otile = (4, 4)          # automatic rule at this size (every queue form: the sorted queue's tile chains start in its steady state)
     want_argb, want_idx = oq.dither(want_pal, dither, tile=otile)
     pal, argb, idx, gparams = _bands_by_hand(nq, img, kind, K, dither, starts, seed, tile)
     assert len(pal) == len(want_pal) and (pal == want_pal).all(), "banded palette differs from the oracle's banded restatement"

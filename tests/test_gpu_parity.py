@@ -258,7 +258,7 @@ def _box8(a):
 
 TILED_VS_SEQ = [("gradient_noise 256^2", lambda: synth.gradient_noise(256, 256, 61), None, 4),       # name, image, seed, automatic tile
                 ("uniform_rgb 224x160", lambda: synth.uniform_rgb(224, 160, 62), None, 4),
-                ("few bins 192^2", lambda: synth.few_colors(192, 192, 63, 2000), None, 64),          # sorted-by-yDiff queue: 64x64
+                ("few bins 192^2", lambda: synth.few_colors(192, 192, 63, 2000), None, 4),           # sorted-by-yDiff queue: tile chains start in its steady state
                 ("bench image 4096^2", lambda: synth.gradient_noise(4096, 4096, 3), 3, 8)]
 
 
