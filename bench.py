@@ -146,6 +146,14 @@ def run_extras(nq, synth, slots, W, H, latency_ms, tile):
         r.update({"workload": "the reference's sample.jpg (495x438 photograph) tiled to %dx%d, slot k: red + k %% 7; PnnLABQuantizer.convert(256, true)" % (W, H),
                   "single_convert_latency_ms": round(lat, 1), "single_image_mpixels_s": round(npx / (lat * 1e-3) / 1e6, 2),
                   "single_convert_stages_ms": {k: round(v, 3) for k, v in st.items()}, "specialised_dither_kernel": int(fast)})
+        # ... and the call the reference's demo app actually makes on it: new PnnQuantizer(path).convert(256, true), the RGB kind
+        # (app/src/main/java/nQuant/android/MainActivity.java:190-194)
+        qr = nq.PnnQuantizer(np.zeros((1, 1), np.int32), mode=nq.MODE_PARALLEL_TILED, seed=3)
+        qr.width, qr.height = W, H
+        lat_rgb = single(qr, pho[0], slots[0])
+        r["rgb_kind_single_convert_latency_ms"] = round(lat_rgb, 1)
+        r["rgb_kind_single_convert_stages_ms"] = {k: round(v, 3) for k, v in qr.stage_ms().items()}
+        del qr
         out["photo"] = r
         for s in slots[:nph]:
             s["q"].set_tile(tile, tile)
