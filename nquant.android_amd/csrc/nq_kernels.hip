@@ -102,15 +102,18 @@ static void launch_gilbert_t(const DevParams& P, const GilbertConsts& G, const T
     const int tilepx = T.tile_w * T.tile_h;
     const bool stage = P.K <= 256 && tilepx <= 256 && !sequential;
     const size_t front = (base + (stage ? (size_t) 64 * tilepx : 0) + 15) & ~(size_t) 15;
-    // sorted-by-yDiff queue: in LDS (48 KB per workgroup) whenever it fits next to the staged palette, else per-lane arrays in scratch
-    if (SORTED && front + NQ_QLDS_BYTES <= 160 * 1024 - 1024) {
+    // sorted-by-yDiff queue: in LDS whenever it fits next to the staged palette, else per-lane arrays in scratch.  The queue holds at
+    // most 15 boxes with DITHER_MAX 9 and 31 with DITHER_MAX 25 (the growth 1 -> 3 -> 7 -> 15 -> 31 stops at the first size >= DITHER_MAX):
+    // 24 or 48 KB per 64-lane workgroup -- with 24 KB four of these one-wavefront workgroups still share a CU (one per SIMD)
+    const size_t qbytes = (size_t) 64 * (G.DITHER_MAX <= 15 ? 16 : NQ_QCAP) * 6 * 4;
+    if (SORTED && front + qbytes <= 160 * 1024 - 1024) {
         if (stage) {
-            allow_big_lds(gilbert_kernel<SORTED, DM, true, SORTED>, front + NQ_QLDS_BYTES);
-            hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, true, SORTED>), dim3(grid), dim3(block), front + NQ_QLDS_BYTES, s, P, G, T, L, d_pixels,
+            allow_big_lds(gilbert_kernel<SORTED, DM, true, SORTED>, front + qbytes);
+            hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, true, SORTED>), dim3(grid), dim3(block), front + qbytes, s, P, G, T, L, d_pixels,
                                d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, d_tile_list);
         } else {
-            allow_big_lds(gilbert_kernel<SORTED, DM, false, SORTED>, front + NQ_QLDS_BYTES);
-            hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, false, SORTED>), dim3(grid), dim3(block), front + NQ_QLDS_BYTES, s, P, G, T, L, d_pixels,
+            allow_big_lds(gilbert_kernel<SORTED, DM, false, SORTED>, front + qbytes);
+            hipLaunchKernelGGL((gilbert_kernel<SORTED, DM, false, SORTED>), dim3(grid), dim3(block), front + qbytes, s, P, G, T, L, d_pixels,
                                d_saliency, d_palette, d_binCache, seed, sequential, d_rng_state, d_index, d_argb, slog, d_tile_list);
         }
         return;

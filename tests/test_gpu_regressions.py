@@ -114,3 +114,20 @@ def test_bin_count_saturates_at_two_to_the_24(nq, oracle, kind, alpha, throws):
     for f in ("hasSemiTransparency", "transparentPixelIndex", "isNano", "texicab", "quan_rt", "maxbins", "ratio", "weight"):
         assert getattr(po, f) == getattr(pg, f), f
     print("cnt saturation kind %d alpha %#x: maxbins %d, stage ms %s" % (kind, alpha, pg.maxbins, gq.stage_ms()))
+
+
+def test_merge_time_limit_has_its_own_status_and_leaves_the_handle_usable(nq):
+    """the wall-clock watchdog of the merge loop must not look like a broken heap.  65 536 bins (BASELINE cfg 2's image)
+    take ~1.5 s of merge loop; with NQ_OPT_MERGE_WALL_SECONDS = 1 the call ends with NQ_ERR_TIME_LIMIT (-6), with the automatic limit the
+    same handle then delivers the palette of the committed cfg 2 fixture."""
+    import os
+    img = synth.uniform_rgb(1024, 1024, 2)
+    want = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_lab256_lookup_uniform_1024x1024.npz"))
+    q = nq.PnnLABQuantizer(img, mode=nq.MODE_PARALLEL_TILED, seed=1)
+    q.set_option(3, 1)                                  # NQ_OPT_MERGE_WALL_SECONDS
+    with pytest.raises(nq.NqError) as ei:
+        q.pnnquan(256)
+    assert ei.value.status == -6 and "time limit" in str(ei.value)
+    q.set_option(3, 0)                                  # automatic again
+    pal = q.pnnquan(256)
+    assert len(pal) == len(want["palette"]) and (pal == want["palette"]).all()
