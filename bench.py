@@ -81,11 +81,9 @@ LOOKUP_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "lookup_traffic.json")
 
 def photo_image(W, H, slot=0):
     """The reference's sample photograph (tests/golden/sample_495x438.npz: decoded pixels of app/src/main/res/drawable/sample.jpg) tiled to
-    W x H; slot k adds k % 7 to the red channel (clipped) so that the images of a batch differ."""
-    rgb = np.load(os.path.join(ROOT, "tests", "golden", "sample_495x438.npz"))["rgb"].astype(np.uint32)
-    r = np.minimum(rgb[..., 0] + np.uint32(slot % 7), np.uint32(255))
-    a = ((np.uint32(255) << np.uint32(24)) | (r << np.uint32(16)) | (rgb[..., 1] << np.uint32(8)) | rgb[..., 2]).view(np.int32)
-    return np.ascontiguousarray(np.tile(a, (H // a.shape[0] + 1, W // a.shape[1] + 1))[:H, :W])
+    W x H; slot k adds k % 7 to the red channel (clipped) so that the images of a batch differ (synth.tile_photo)."""
+    from nquant.android_amd import synth
+    return synth.tile_photo(np.load(os.path.join(ROOT, "tests", "golden", "sample_495x438.npz"))["rgb"], W, H, slot)
 
 
 def run_extras(nq, synth, slots, W, H, latency_ms, tile):

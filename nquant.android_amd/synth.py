@@ -93,6 +93,15 @@ def flat_with_patch(side, alpha, seed, patch=160, rgb=0x336698):
     return img
 
 
+def tile_photo(rgb, width, height, slot=0):
+    """A decoded photograph (uint8 [h][w][3], e.g. tests/golden/sample_495x438.npz) tiled to width x height opaque ARGB pixels; slot k adds
+    k % 7 to the red channel (clipped) so that the images of a batch differ.  bench.py's `photo` workload and its parity test."""
+    rgb = np.asarray(rgb).astype(np.uint32)
+    r = np.minimum(rgb[..., 0] + np.uint32(slot % 7), np.uint32(255))
+    a = ((np.uint32(255) << np.uint32(24)) | (r << np.uint32(16)) | (rgb[..., 1] << np.uint32(8)) | rgb[..., 2]).view(np.int32)
+    return np.ascontiguousarray(np.tile(a, (height // a.shape[0] + 1, width // a.shape[1] + 1))[:height, :width])
+
+
 def gradient_noise_torch(width, height, seed, device="cuda", noise=24, row0=0, rows=None):
     """gradient_noise() generated on the device with torch (bench.py fills a whole batch of distinct images this way): the same
     integer stream and float64 formulae; a device sin() that differs from numpy's in the last place can move a blue value that

@@ -264,3 +264,36 @@ def test_rgb_kind_through_the_specialised_kernel(nq, oracle, K, mk, tile, handed
         bad = (got_idx.astype(np.int32) != want_idx).sum()
         assert bad == 0, "fast=%d: index mismatches %d of %d (tiles handed back: %d)" % (fast, bad, want_idx.size, handed_back)
         assert (got_argb != want_argb).sum() == 0
+
+
+def test_photo_workload_4096_palette_and_rows_vs_oracle(nq, oracle):
+    """bench.py's `photo` workload at its full size -- the reference's sample photograph tiled to 4096^2 (2970 bins: weight 0.086, the
+    sorted-by-yDiff queue with DITHER_MAX 9, generic kernel, automatic 8x8 tiles whose chains start in the queue's steady state, the
+    LDS-resident PriorityQueue) -- palette, scalars and four tile rows (2048 tiles) against the oracle, for both quantizer kinds."""
+    import os
+    import torch
+    W = H = 4096
+    rgb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_495x438.npz"))["rgb"]
+    img = synth.tile_photo(rgb, W, H, 3)
+    seed = 3
+    d_in = torch.from_numpy(img.reshape(-1)).cuda()
+    for kind in (1, 0):
+        oq, pal = _oracle_palette(oracle, kind, img, 256)
+        oq.set_seed(seed)
+        q = (nq.PnnLABQuantizer if kind else nq.PnnQuantizer)(np.zeros((1, 1), np.int32), mode=TILED, seed=seed)
+        q.width, q.height = W, H
+        d_out = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+        d_idx = torch.zeros(W * H, dtype=torch.int16, device="cuda")
+        gpal = q.convert_device(d_in.data_ptr(), 256, True, d_out.data_ptr(), d_idx.data_ptr())
+        torch.cuda.synchronize()
+        assert len(gpal) == len(pal) and (gpal == pal).all(), "kind %d: palette differs from the oracle" % kind
+        po, pg = oq.params, q.params
+        assert (po.maxbins, po.quan_rt, po.isNano, po.texicab, po.weight, po.ratio) == (pg.maxbins, pg.quan_rt, pg.isNano, pg.texicab, pg.weight, pg.ratio)
+        assert q.dither_path()[0] == 0                    # sorted queue: the generic kernel
+        idx = d_idx.cpu().numpy().view(np.uint16).reshape(H, W).astype(np.int32)
+        out = d_out.cpu().numpy().reshape(H, W)
+        for r in (0, 54, 300, 511):                       # (row 54: a tile row that straddles two copies of the picture)
+            want_argb, want_idx = oq.dither_tile_rows(pal, True, (8, 8), r, 1)
+            ys = slice(r * 8, r * 8 + 8)
+            assert (idx[ys] == want_idx[ys]).all(), "kind %d tile row %d differs from the oracle" % (kind, r)
+            assert (out[ys] == want_argb[ys]).all()
