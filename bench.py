@@ -357,9 +357,11 @@ def main():
     single_stages = q0.stage_ms()
     # the same convert once more with the STAMPED build of the merge kernel (NQ_MERGE_STATS=1: phase ticks for "merge_stats"; ~4 % slower, untimed)
     os.environ["NQ_MERGE_STATS"] = "1"
-    q0.convert_device(slots[0]["in"].data_ptr(), 256, True, slots[0]["out"].data_ptr(), slots[0]["idx"].data_ptr())
-    torch.cuda.synchronize()
-    del os.environ["NQ_MERGE_STATS"]
+    try:
+        q0.convert_device(slots[0]["in"].data_ptr(), 256, True, slots[0]["out"].data_ptr(), slots[0]["idx"].data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["NQ_MERGE_STATS"]
     single_merge_stats = q0.merge_stats()
     run_all(args.warmup, False)
 
