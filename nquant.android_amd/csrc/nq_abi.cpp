@@ -284,7 +284,11 @@ int upload_palette(nq_handle* h, const uint32_t* palette, int K) {
 void* packed_lists(nq_handle* h) { return h->sc->cell_lists.p + 2 * (size_t) 65536 * 32 + 2 * 65536; }
 
 // candidate lists per colour cell for this palette (nq_lists.inc); empty view = full scans
-int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
+// sal_pixels != null: the saliency map of these n pixels is wanted in h->sc->saliency as well; *sal_done says whether it was built here
+// (beside the LAB list builders, one launch) or is left to the caller
+int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out, const int* sal_pixels = nullptr, int64_t sal_n = 0, int sal_subst = 0,
+                  bool* sal_done = nullptr) {
+    if (sal_done) *sal_done = false;
     out->closest = out->closestCount = out->nearest = out->nearestCount = nullptr;
     if (!h->use_lists || P.K > 256 || P.K < 8) return NQ_OK;
     const size_t LB = (size_t) 65536 * 32;
@@ -310,7 +314,10 @@ int prepare_lists(nq_handle* h, const DevParams& P, nq::ListsView* out) {
         launch_cell_lab_box(h->sc->cell_box.p, h->stream);
         h->sc->cell_box_ready = true;
     }
-    launch_build_lists(P, h->d_palette.p, wA, wR, wG, wB, nearest, h->sc->cell_box.p, base, base + 2 * LB, base + LB, base + 2 * LB + 65536, h->stream);
+    if (sal_pixels) NQ_HIP(h, h->sc->saliency.reserve((size_t) sal_n));
+    const bool sal_built = launch_build_lists(P, h->d_palette.p, wA, wR, wG, wB, nearest, h->sc->cell_box.p, base, base + 2 * LB, base + LB,
+                                              base + 2 * LB + 65536, h->stream, sal_pixels, sal_n, sal_pixels ? h->sc->saliency.p : nullptr, sal_subst);
+    if (sal_done) *sal_done = sal_built;
     // (a negative ratio makes the closest error non-monotone in its terms: the list argument does not hold, full scans)
     if (!(h->kind == NQ_KIND_LAB && P.ratio < 0)) { out->closest = base; out->closestCount = base + 2 * LB; }
     if (nearest) { out->nearest = base + LB; out->nearestCount = base + 2 * LB + 65536; }
@@ -797,12 +804,14 @@ int dither_device(nq_handle* h, const uint32_t* d_argb, int width, int height, c
     }
     if (sequential && !ov.blue_only) NQ_HIP(h, hipMemsetAsync(h->d_bincache.p, 0xFF, 65536 * sizeof(short), h->stream));   // (BlueNoise.dither alone continues the caches)
     nq::ListsView lv;
-    { int rcl = prepare_lists(h, P, &lv); if (rcl) return rcl; }
+    bool sal_done = false;
+    const bool want_sal = !staged && hasSal;            // (the map of THIS call's pixels; the builders and the map share one launch where they can)
+    { int rcl = prepare_lists(h, P, &lv, want_sal ? (const int*) d_argb : nullptr, n, salSubst ? 1 : 0, &sal_done); if (rcl) return rcl; }
     const float* d_sal = nullptr;
     if (staged) d_sal = hasSal ? ov.d_sal : nullptr;
     else if (hasSal) {
         NQ_HIP(h, h->sc->saliency.reserve((size_t) n));
-        launch_saliency(P, salSubst ? 1 : 0, (const int*) d_argb, n, h->sc->saliency.p, h->stream);
+        if (!sal_done) launch_saliency(P, salSubst ? 1 : 0, (const int*) d_argb, n, h->sc->saliency.p, h->stream);
         d_sal = h->sc->saliency.p;
     }
     rec(h, 5);       // stage "palette_fill" ends here: it includes the candidate-list build and the saliency map

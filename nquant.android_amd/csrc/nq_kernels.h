@@ -56,9 +56,14 @@ struct ListsView {
 };
 // wA..wB: total weight of da^2, dr^2, dg^2, db^2 in closestColorIndex's err; nearest: also build the nearestColorIndex lists
 void launch_cell_lab_box(float* d_box /* [65536][6] */, hipStream_t s);
-void launch_build_lists(const DevParams& P, const int* d_palette, double wA, double wR, double wG, double wB, bool nearest,
+// a saliency map to build beside the LAB candidate lists (the three passes are independent; one launch, nq_dither.inc build_lab_lists_kernel)
+struct SalJob { const int* pixels; long long N; float* out; long long vec4; int salSubst; int blocks; };
+// d_sal_pixels != null: the saliency map of these N pixels is wanted too -- returns true when it went into the same launch (LAB with
+// nearest lists), false when the caller has to launch_saliency itself
+bool launch_build_lists(const DevParams& P, const int* d_palette, double wA, double wR, double wG, double wB, bool nearest,
                         const float* d_box, unsigned char* d_closest, unsigned char* d_closestCount, unsigned char* d_nearest,
-                        unsigned char* d_nearestCount, hipStream_t s);
+                        unsigned char* d_nearestCount, hipStream_t s, const int* d_sal_pixels = nullptr, int64_t N = 0, float* d_sal_out = nullptr,
+                        int salSubst = 0);
 void launch_saliency(const DevParams& P, int salSubst, const int* d_pixels, int64_t N, float* d_out, hipStream_t s);
 
 void launch_nearest_index(const DevParams& P, const int* d_palette, const ListsView& lv, const int* d_colors, int64_t M, short* d_out, hipStream_t s);

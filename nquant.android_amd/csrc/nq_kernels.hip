@@ -4,6 +4,7 @@
 #include "nq_device.h"
 #include "nq_kernels.h"
 #include <cstring>
+#include <algorithm>
 #include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -52,19 +53,29 @@ void launch_cell_lab_box(float* d_box, hipStream_t s) {
     hipLaunchKernelGGL(cell_lab_box_kernel, dim3(65536 / 256), dim3(256), 0, s, d_box);
 }
 
-void launch_build_lists(const DevParams& P, const int* d_palette, double wA, double wR, double wG, double wB, bool nearest,
+bool launch_build_lists(const DevParams& P, const int* d_palette, double wA, double wR, double wG, double wB, bool nearest,
                         const float* d_box, unsigned char* d_closest, unsigned char* d_closestCount, unsigned char* d_nearest,
-                        unsigned char* d_nearestCount, hipStream_t s) {
+                        unsigned char* d_nearestCount, hipStream_t s, const int* d_sal_pixels, int64_t N, float* d_sal_out, int salSubst) {
+    if (nearest && P.kind == 1) {          // LAB: both builders (and the saliency map, if one is wanted) side by side in one launch
+        SalJob sal;
+        std::memset(&sal, 0, sizeof sal);
+        if (d_sal_pixels && d_sal_out && N > 0) {
+            sal.pixels = d_sal_pixels; sal.N = (long long) N; sal.out = d_sal_out; sal.salSubst = salSubst;
+            sal.vec4 = (((uintptr_t) d_sal_pixels | (uintptr_t) d_sal_out) & 15) ? 0 : (long long) (N / 4);
+            sal.blocks = grid_for(N / 4 + 1, 256, 256 * 8);
+        }
+        const size_t smem = std::max(palette_smem_bytes(P.kind, P.K), (size_t) 256 * sizeof(double));
+        allow_big_lds(build_lab_lists_kernel, smem);
+        hipLaunchKernelGGL(build_lab_lists_kernel, dim3(2 * 65536 / 256 + sal.blocks), dim3(256), smem, s, P, d_palette,
+                           wA, wR, wG, wB, P.hasAlpha ? 1 : 0, d_box, d_closest, d_closestCount, d_nearest, d_nearestCount, sal);
+        return sal.blocks > 0;
+    }
     hipLaunchKernelGGL(build_closest_lists_kernel, dim3(65536 / 256), dim3(256), 0, s, P, d_palette,
                        wA, wR, wG, wB, d_closest, d_closestCount);
-    if (nearest && P.kind == 1) {
-        allow_big_lds(build_nearest_lists_kernel, palette_smem_bytes(P.kind, P.K));
-        hipLaunchKernelGGL(build_nearest_lists_kernel, dim3(65536 / 256), dim3(256), palette_smem_bytes(P.kind, P.K), s, P, d_palette,
-                           P.hasAlpha ? 1 : 0, d_box, d_nearest, d_nearestCount);
-    }
-    else if (nearest)      // RGB: the nearestColorIndex weights are pa, pr, pg, pb themselves
+    if (nearest)           // RGB: the nearestColorIndex weights are pa, pr, pg, pb themselves
         hipLaunchKernelGGL(build_nearest_rgb_lists_kernel, dim3(65536 / 256), dim3(256), (size_t) P.K * sizeof(int), s, P, d_palette,
                            P.K < 3 ? 1.0 : P.PA, P.K < 3 ? 1.0 : P.PR, P.K < 3 ? 1.0 : P.PG, P.K < 3 ? 1.0 : P.PB, d_nearest, d_nearestCount);
+    return false;
 }
 
 void launch_saliency(const DevParams& P, int salSubst, const int* d_pixels, int64_t N, float* d_out, hipStream_t s) {
