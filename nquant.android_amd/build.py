@@ -14,7 +14,7 @@ TAG = os.environ.get("NQ_BUILD_TAG", "")
 if TAG:
     LIB = os.path.join(HERE, "libnquant_hip.%s.so" % TAG)
 EXTRA_DEFS = os.environ.get("NQ_BUILD_DEFS", "").split()
-COMMON = (["-g"] if os.environ.get("NQ_BUILD_DEBUG") else []) + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+COMMON = (["-g"] if os.environ.get("NQ_BUILD_DEBUG") else []) + ["-O3", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 INC = os.path.join("..", "..", "include")
 # object -> (kind, sources it is rebuilt for)
 UNITS = {
@@ -73,7 +73,7 @@ def build(force=False, verbose=False):
         with open(STAMP, "w") as f:
             f.write(flags)
     if procs or force or _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

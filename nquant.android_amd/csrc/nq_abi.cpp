@@ -15,6 +15,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <thread>
 
 using namespace nq;
 
@@ -186,7 +187,7 @@ struct nq_handle {
     DevBuf<unsigned short> ring_index[3];
     hipStream_t copy_stream = nullptr;
     hipStream_t lane_stream = nullptr;  // second lane of the batch entry points
-    hipStream_t more_lanes[2] = {nullptr, nullptr};   // ... third and fourth
+    hipStream_t more_lanes[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ... third to eighth
     long long merge_stats[16] = {0};
     std::vector<uint32_t> dev_palette;  // what d_palette holds, as far as the host knows (empty: unknown): an upload of the same entries is skipped
     uint32_t* fetched_palette = nullptr; int fetched_len = 0;      // palette_fetch -> palette_check
@@ -1188,10 +1189,10 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
         if (i) NQ_HIP(h0, hipStreamSynchronize(hs[i]->stream));
     }
     if (n > 1 && !h0->lane_stream) NQ_HIP(h0, hipStreamCreateWithFlags(&h0->lane_stream, hipStreamNonBlocking));
-    int L = std::min(n, 4);          // (measured on 1024 images of 4096^2: prepare phase 640 / 557 / 552 / 543 us per image with 1 / 2 / 3 / 4 lanes)
-    if (const char* f = std::getenv("NQ_BATCH_LANES")) { const int t = std::atoi(f); if (t >= 1 && t <= 4) L = std::min(t, n); }
-    hipStream_t lane_s[4] = {h0->stream, n > 1 ? h0->lane_stream : h0->stream, nullptr, nullptr};
-    Scratch* lane_sc[4] = {&h0->own, n > 1 ? &hs[1]->own : &h0->own, nullptr, nullptr};
+    int L = std::min(n, 4);          // (measured on 1024 images of 4096^2, ONE issuing thread: prepare phase 640 / 557 / 552 / 543 us per image with 1 / 2 / 3 / 4 lanes)
+    if (const char* f = std::getenv("NQ_BATCH_LANES")) { const int t = std::atoi(f); if (t >= 1 && t <= 8) L = std::min(t, n); }
+    hipStream_t lane_s[8] = {h0->stream, n > 1 ? h0->lane_stream : h0->stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    Scratch* lane_sc[8] = {&h0->own, n > 1 ? &hs[1]->own : &h0->own, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     for (int k = 2; k < L; ++k) {
         if (!h0->more_lanes[k - 2]) NQ_HIP(h0, hipStreamCreateWithFlags(&h0->more_lanes[k - 2], hipStreamNonBlocking));
         lane_s[k] = h0->more_lanes[k - 2]; lane_sc[k] = &hs[k]->own;
@@ -1200,11 +1201,27 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
     std::vector<PaletteJob> jobs(n);
     std::vector<const PaletteJob*> jp(n);
     (void) hipEventRecord(h0->bev[0], lane_s[0]);
-    for (int i = 0; i < n; ++i) {
-        int rc = pnnquan_prepare(hs[i], d_argb[i], widths[i], heights[i], nMaxColors, out_palettes + (size_t) i * palette_stride,
-                                 out_K + i, &jobs[i]);
-        if (rc) return fail_from(hs[i], rc);
-        jp[i] = &jobs[i];
+    {
+        // One host thread per lane (round 4): pnnquan_prepare waits twice for the device per image (the pre-scan's scalars, the bin count),
+        // and a single issuing thread that blocks there leaves the other lanes without new work -- only two images ever overlapped.  Lane k's
+        // thread walks the images k, k + L, ... in order (they share lane k's scratch); handles, streams and scratch sets of different lanes
+        // are disjoint, the launch-error slot is per thread.
+        std::vector<int> lane_rc(L, NQ_OK), lane_bad(L, -1);
+        auto lane_work = [&](int k) {
+            if (hipSetDevice(h0->device) != hipSuccess) { lane_rc[k] = NQ_ERR_HIP; lane_bad[k] = k; return; }
+            for (int i = k; i < n; i += L) {
+                const int rc = pnnquan_prepare(hs[i], d_argb[i], widths[i], heights[i], nMaxColors, out_palettes + (size_t) i * palette_stride,
+                                               out_K + i, &jobs[i]);
+                if (rc) { lane_rc[k] = rc; lane_bad[k] = i; return; }
+                jp[i] = &jobs[i];
+            }
+        };
+        std::vector<std::thread> workers;
+        for (int k = 1; k < L; ++k) workers.emplace_back(lane_work, k);
+        lane_work(0);
+        for (auto& t : workers) t.join();
+        for (int k = 0; k < L; ++k)
+            if (lane_rc[k]) return fail_from(hs[lane_bad[k] >= 0 && lane_bad[k] < n ? lane_bad[k] : 0], lane_rc[k]);
     }
     for (int k = 1; k < L; ++k) NQ_HIP(h0, hipStreamSynchronize(lane_s[k]));          // every prepare has been issued: join before the merge launch
     (void) hipEventRecord(h0->bev[1], lane_s[0]);
