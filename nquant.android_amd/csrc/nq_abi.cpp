@@ -16,6 +16,7 @@
 #include <utility>
 #include <vector>
 #include <thread>
+#include <exception>
 
 using namespace nq;
 
@@ -1172,10 +1173,10 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
         if (hs[i]->device != h0->device) NQ_FAIL(h0, NQ_ERR_INVALID, "handles of a batch must share one device");
         for (int j = 0; j < i; ++j) if (hs[j] == hs[i]) NQ_FAIL(h0, NQ_ERR_INVALID, "a handle appears twice in the batch");
     }
-    // The per-image stages in front of the merge loops run on up to FOUR lanes (image i: stream and per-pixel scratch of lane i % 4;
-    // the scratch is that of the first four handles): while the host waits for a read-back of one image, and while a kernel with a
+    // The per-image stages in front of the merge loops run on FOUR lanes by default, eight at most (image i: stream and per-pixel scratch of
+    // lane i % L; the scratch is that of the first L handles): while the host waits for a read-back of one image, and while a kernel with a
     // long tail or a small grid runs (the fullest bin's chain of the histogram, the list compactions), the queued kernels of the
-    // other lanes keep the GPU busy (NQ_BATCH_LANES = 1..4 overrides).  The merge launch joins the lanes.
+    // other lanes keep the GPU busy (NQ_BATCH_LANES = 1..8 overrides).  The merge launch joins the lanes.
     struct Restore {
         nq_handle* const* hs; int n; std::vector<hipStream_t> streams;
         ~Restore() { for (int i = 0; i < n; ++i) { hs[i]->stream = streams[i]; hs[i]->sc = &hs[i]->own; hs[i]->light_events = false; } }
@@ -1217,8 +1218,12 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
             }
         };
         std::vector<std::thread> workers;
-        for (int k = 1; k < L; ++k) workers.emplace_back(lane_work, k);
+        std::vector<int> inline_lanes;                   // (a lane whose thread could not be created is walked by the caller's thread)
+        for (int k = 1; k < L; ++k) {
+            try { workers.emplace_back(lane_work, k); } catch (const std::exception&) { inline_lanes.push_back(k); }
+        }
         lane_work(0);
+        for (int k : inline_lanes) lane_work(k);
         for (auto& t : workers) t.join();
         for (int k = 0; k < L; ++k)
             if (lane_rc[k]) return fail_from(hs[lane_bad[k] >= 0 && lane_bad[k] < n ? lane_bad[k] : 0], lane_rc[k]);

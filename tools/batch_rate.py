@@ -34,7 +34,9 @@ print("loops that gave up on their helpers at least once: %d of %d (%d times in 
     sum(1 for t in tss if t["gave_up"]), B, sum(t["gave_up"] for t in tss), sum(1 for t in tss if t["helpers"] > 0 and not t["speculating_at_end"])))
 if not st["find_ticks_100MHz"]:
     print("(the batch variants of the merge kernel carry no phase stamps: NQ_MERGE_STATS=1 selects the stamped 128-thread build)")
-busy = sorted((q.merge_stats()["find_ticks_100MHz"] + q.merge_stats()["ctrl_ticks_100MHz"]) / 1e5 for q in qs)
-print("loop busy time (find + control) ms: min %.0f median %.0f p99 %.0f max %.0f | batch phases %s" % (busy[0], busy[len(busy) // 2], busy[int(len(busy) * 0.99)], busy[-1], qs[0].batch_phase_ms()))
+print("batch phases %s" % qs[0].batch_phase_ms())
+if st["find_ticks_100MHz"] > 0 and st["ctrl_ticks_100MHz"] > 0:          # (stamped build only: without stamps the tick fields hold no times)
+    busy = sorted((q.merge_stats()["find_ticks_100MHz"] + q.merge_stats()["ctrl_ticks_100MHz"]) / 1e5 for q in qs)
+    print("loop busy time (find + control) ms: min %.0f median %.0f p99 %.0f max %.0f" % (busy[0], busy[len(busy) // 2], busy[int(len(busy) * 0.99)], busy[-1]))
 print("image 0 control ms: total %.1f | sifts %.1f (pops %d) merges %.1f top fetch %.1f find epilogues %.1f (incl. their sift)" % (
     st["ctrl_ticks_100MHz"] / 1e5, ts["sift_ticks"] / 1e5, ts["pops"], ts["merge_ticks"] / 1e5, ts["top_fetch_ticks"] / 1e5, ts["epilogue_ticks"] / 1e5))

@@ -88,7 +88,7 @@ if want latency; then
 fi
 if want rgb; then
   # 8. the RGB quantizer
-  { python3 tools/batch_rate.py 1536 0 2>&1 | grep -E "^kind|busy|gave up" | tail -3; python3 tools/latency.py 4096 0 2>&1 | grep -v amdgpu.ids; python3 tools/latency.py 4096 0 uniform 2>&1 | grep -v amdgpu.ids; } > $O/rgb_kind.txt
+  { python3 tools/batch_rate.py 1536 0 2>&1 | grep -E "^kind|batch phases|gave up" | tail -3; python3 tools/latency.py 4096 0 2>&1 | grep -v amdgpu.ids; python3 tools/latency.py 4096 0 uniform 2>&1 | grep -v amdgpu.ids; } > $O/rgb_kind.txt
   cat $O/rgb_kind.txt
 fi
 if want scaling; then
