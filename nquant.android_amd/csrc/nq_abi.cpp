@@ -1209,13 +1209,20 @@ int nq_convert_batch_device(nq_handle* const* hs, int n, const uint32_t* const* 
         // are disjoint, the launch-error slot is per thread.
         std::vector<int> lane_rc(L, NQ_OK), lane_bad(L, -1);
         auto lane_work = [&](int k) {
-            if (hipSetDevice(h0->device) != hipSuccess) { lane_rc[k] = NQ_ERR_HIP; lane_bad[k] = k; return; }
-            for (int i = k; i < n; i += L) {
-                const int rc = pnnquan_prepare(hs[i], d_argb[i], widths[i], heights[i], nMaxColors, out_palettes + (size_t) i * palette_stride,
-                                               out_K + i, &jobs[i]);
-                if (rc) { lane_rc[k] = rc; lane_bad[k] = i; return; }
-                jp[i] = &jobs[i];
-            }
+            int at = k;
+            try {                                        // (nothing may leave a lane's thread: an escaping exception would end the process)
+                if (hipSetDevice(h0->device) != hipSuccess) { lane_rc[k] = NQ_ERR_HIP; lane_bad[k] = k; hs[k]->err = "hipSetDevice failed in a batch lane"; return; }
+                for (int i = k; i < n; i += L) {
+                    at = i;
+                    const int rc = pnnquan_prepare(hs[i], d_argb[i], widths[i], heights[i], nMaxColors, out_palettes + (size_t) i * palette_stride,
+                                                   out_K + i, &jobs[i]);
+                    if (rc) { lane_rc[k] = rc; lane_bad[k] = i; return; }
+                    jp[i] = &jobs[i];
+                }
+            } catch (const std::exception& e) {
+                lane_rc[k] = NQ_ERR_HIP; lane_bad[k] = at;
+                try { hs[at]->err = std::string("exception in a batch lane: ") + e.what(); } catch (...) {}
+            } catch (...) { lane_rc[k] = NQ_ERR_HIP; lane_bad[k] = at; }
         };
         std::vector<std::thread> workers;
         std::vector<int> inline_lanes;                   // (a lane whose thread could not be created is walked by the caller's thread)
