@@ -135,7 +135,7 @@ struct Scratch {
     DevBuf<unsigned short> keys_a, keys_b;
     DevBuf<int> vals_a, vals_b;
     DevBuf<unsigned char> sort_tmp;
-    DevBuf<unsigned> seg;             // start[65536], end[65536], counter (+ padding), list of the occupied bins[65536]
+    DevBuf<unsigned> seg;             // start[65536], end[65536], counters (+ padding), list of the occupied bins[65536], of the fat bins[1024]
     DevBuf<double> hist;              // [65536][5]
     DevBuf<int> init_cand;            // initial LAB pass: candidate lists {bin, bound}[65536][128], then the counts [65536]
     DevBuf<unsigned char> cell_lists; // closest lists, nearest lists (65536 x 32 each), then their counts (65536 each)
@@ -355,7 +355,7 @@ nq::Bins bins_of(nq_handle* h) {
 int reserve_palette_ws(nq_handle* h, int64_t n) {
     NQ_HIP(h, h->sc->vals_a.reserve((size_t) n)); NQ_HIP(h, h->sc->vals_b.reserve((size_t) n));
     NQ_HIP(h, h->sc->sort_tmp.reserve(sort_temp_bytes(n) + 256));
-    NQ_HIP(h, h->sc->seg.reserve(3 * 65536 + 64));     // start[65536], end[65536], occupied-bin counter, occupied-bin list[65536]
+    NQ_HIP(h, h->sc->seg.reserve(3 * 65536 + 64 + 1024));     // start[65536], end[65536], counters, occupied-bin list[65536], fat-bin list[1024]
     NQ_HIP(h, h->sc->hist.reserve((size_t) 65536 * 5));
     if (h->kind == 1) NQ_HIP(h, h->sc->init_cand.reserve((size_t) 65536 * 128 * 2 + 65536));
     NQ_HIP(h, h->binf.reserve((size_t) 6 * 65536)); NQ_HIP(h, h->bind.reserve((size_t) 4 * 65536));

@@ -128,7 +128,7 @@ struct SortWorkspace {
     int *vals_a, *vals_b;            // [n] each: the packed words before / after the sort
     void* tmp; size_t tmp_bytes;
     unsigned *seg_start, *seg_end;   // [65536] each, contiguous (seg_end = seg_start + 65536), followed by the occupied-bin counter (seg_end[65536])
-                                     // and, 64 words further, the list of the occupied bins [65536]
+                                     // and, 64 words further, the list of the occupied bins [65536] and that of the fat bins [1024]
 };
 size_t sort_temp_bytes(int64_t n);
 size_t sort32_temp_bytes(int64_t n, bool pairs);

@@ -235,17 +235,30 @@ void launch_histogram(int kind, const int* d_pixels, int64_t n, const HistParams
         hipLaunchKernelGGL(bin_keys_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, d_pixels, (long long) n, hp, pk_a);
     size_t tmp = ws.tmp_bytes;
     (void) rocprim::radix_sort_keys<HistSortConfig>(ws.tmp, tmp, (const unsigned*) pk_a, pk_b, (size_t) n, 16, 32, s);
-    unsigned* const occ_count = ws.seg_end + 65536;
+    unsigned* const occ_count = ws.seg_end + 65536;             // [0] occupied bins, [1] fat bins
     unsigned* const occ_list = occ_count + 64;
-    (void) hipMemsetAsync(occ_count, 0, sizeof(unsigned), s);
-    hipLaunchKernelGGL(occupied_bins_kernel, dim3(64), dim3(1024), 0, s, (const unsigned*) pk_b, (unsigned) n, ws.seg_start, ws.seg_end, occ_count, occ_list, d_hist);
+    unsigned* const fat_list = occ_list + 65536;                // [NQ_FAT_CAP]
+    // RGB kind: a bin is "fat" (a workgroup of its own, hist_fat_rgb_kernel) from 16 384 pixels up; never more than NQ_FAT_CAP - 1 of them
+    unsigned fat_min = 0xFFFFFFFFu;
+    if (kind != 1) {
+        fat_min = 16384u;
+        if (const char* f = std::getenv("NQ_HIST_FAT_MIN")) { const long t = std::atol(f); if (t >= 1) fat_min = (unsigned) std::min<long>(t, 0x7FFFFFFFL); }
+        fat_min = std::max(fat_min, (unsigned) (n / NQ_FAT_CAP) + 1u);
+    }
+    (void) hipMemsetAsync(occ_count, 0, 2 * sizeof(unsigned), s);
+    hipLaunchKernelGGL(occupied_bins_kernel, dim3(64), dim3(1024), 0, s, (const unsigned*) pk_b, (unsigned) n, ws.seg_start, ws.seg_end, occ_count, occ_list, d_hist,
+                       fat_min, fat_list);
     const int keyfmt = hp.hasSemi ? 2 : hp.hasTransp ? 1 : 0;          // getColorIndex: 4-4-4-4 / 1-5-5-5 / 5-6-5
     if (kind == 1)
         hipLaunchKernelGGL(hist_segments_kernel<1>, dim3(65536 / 4), dim3(256), keyfmt == 2 ? 0 : (size_t) 4 * (keyfmt == 0 ? 256 : 512) * 16, s,
-                           (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt, (const unsigned*) occ_count, (const unsigned*) occ_list);
-    else
+                           (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt, (const unsigned*) occ_count, (const unsigned*) occ_list, fat_min);
+    else {
+        // the fat bins first (usually none: the workgroups leave at once), then one wavefront per ordinary bin
+        hipLaunchKernelGGL(hist_fat_rgb_kernel, dim3(NQ_FAT_WGS), dim3(256), 0, s,
+                           (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt, (const unsigned*) occ_count, (const unsigned*) fat_list);
         hipLaunchKernelGGL(hist_segments_kernel<0>, dim3(65536 / 4), dim3(256), 0, s, (const unsigned*) pk_b, ws.seg_start, ws.seg_end, d_hist, keyfmt,
-                           (const unsigned*) occ_count, (const unsigned*) occ_list);
+                           (const unsigned*) occ_count, (const unsigned*) occ_list, fat_min);
+    }
 }
 void launch_compact(int kind, const double* d_hists, int n_bands, const Bins& B, int* d_maxbins, int* d_blockcnt, hipStream_t s) {
     hipLaunchKernelGGL(compact_count_kernel, dim3(64), dim3(1024), 0, s, d_hists, n_bands, d_blockcnt);

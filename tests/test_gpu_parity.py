@@ -112,6 +112,23 @@ def test_pnnquan_palette_and_scalars_bit_exact(nq, oracle, kind, K, mk):
     assert (got != want).sum() == 0, "palette mismatches: %d of %d" % ((got != want).sum(), len(want))
 
 
+@pytest.mark.parametrize("variant,fat_min", [(0, 64), (1, 100), (2, 1000), (3, 64)])
+def test_fat_bins_take_the_workgroup_per_bin_histogram(nq, oracle, monkeypatch, variant, fat_min):
+    """RGB kind: bins of NQ_HIST_FAT_MIN pixels and more (default 16 384) leave hist_segments_kernel for hist_fat_rgb_kernel
+    (csrc/nq_palette.inc), where a whole workgroup strides over the bin (exact integer sums).  Forced here on small images: ~2300-pixel
+    bins under the three key forms, and a semi-transparent image (4-4-4-4 keys).  (The LAB kind keeps one wavefront per bin: its float32
+    chain is sequential, nq_palette.inc.)"""
+    monkeypatch.setenv("NQ_HIST_FAT_MIN", str(fat_min))
+    img = _crowded_bins(variant) if variant < 3 else synth.with_alpha(_crowded_bins(0), 7)
+    oq, want = _oracle_palette(oracle, 0, img, 16)
+    gq = nq.PnnQuantizer(img)
+    got = gq.pnnquan(16)
+    assert oq.params.maxbins == gq.params.maxbins
+    assert len(got) == len(want) and (got == want).all()
+    monkeypatch.delenv("NQ_HIST_FAT_MIN")
+    assert (nq.PnnQuantizer(img).pnnquan(16) == want).all()
+
+
 def _lab_of(oracle, argb):
     u, inv = np.unique(argb.reshape(-1), return_inverse=True)
     lab = np.array([oracle.rgb2lab(int(c))[1:] for c in u], np.float64)
