@@ -255,8 +255,8 @@ int nq_get_merge_stats(const nq_handle* h, int64_t* out16);
 /* Counters of the last merge loop's TEAM (csrc/nq_merge.inc: a merge loop that has CUs to spare -- a single image, a batch of up to 128 -- runs as a master
  * workgroup plus 1 - 7 helper workgroups that evaluate find_nn speculatively for the bins that will surface next), 16 values:
  * {work records published, helper results used in place of an own find_nn, waits for a result that timed out, 100 MHz ticks spent
- * waiting, helpers per loop, 1 if the loop was still speculating at its end, bin-info cache hits for the heap top, ... for the merged
- * neighbour, then the control thread's 100 MHz ticks in heap sifts / in merges / fetching the heap top's bin, the deleted nodes
+ * waiting, helpers per loop, 1 if the loop was still speculating at its end, bin-info cache hits for the heap top, results used that were
+ * computed for a merge before it happened ("virtual merge"), then the control thread's 100 MHz ticks in heap sifts / in merges / fetching the heap top's bin, the deleted nodes
  * popped, ticks in the find_nn epilogues, ticks spent choosing work records, results a helper declined (RGB), times the loop gave up
  * on its helpers for a while}.  Diagnostics. */
 int nq_get_team_stats(const nq_handle* h, int64_t* out16);

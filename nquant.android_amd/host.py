@@ -230,7 +230,7 @@ class PnnQuantizer:
         """Counters of the last merge loop's team of helper workgroups (nq_get_team_stats)."""
         a = (C.c_int64 * 16)()
         self._check(self._L.nq_get_team_stats(self._h, a))
-        return dict(zip(["published", "used", "timeouts", "wait_ticks_100MHz", "helpers", "speculating_at_end", "cache_hits_top", "cache_hits_neighbour",
+        return dict(zip(["published", "used", "timeouts", "wait_ticks_100MHz", "helpers", "speculating_at_end", "cache_hits_top", "virtual_merges_used",
                          "sift_ticks", "merge_ticks", "top_fetch_ticks", "pops", "epilogue_ticks", "select_ticks", "declined", "gave_up"], list(a)))
 
     def batch_phase_ms(self):

@@ -27,7 +27,7 @@ print("overflows %d rebuilds %d ratio %.4f" % (st["overflows"], st["rebuilds"], 
 ts = q.team_stats()
 print("team: helpers %d published %d used %d timeouts %d wait %.2f us per used result, speculating at end %d" % (
     ts["helpers"], ts["published"], ts["used"], ts["timeouts"], ts["wait_ticks_100MHz"] / max(ts["used"] + ts["timeouts"], 1) / 100, ts["speculating_at_end"]))
-print("bin-info cache: top hits %d, neighbour hits %d | helpers declined %d results, given up on %d times" % (ts["cache_hits_top"], ts["cache_hits_neighbour"], ts["declined"], ts["gave_up"]))
+print("bin-info cache: top hits %d | results of virtual merges used %d | helpers declined %d results, given up on %d times" % (ts["cache_hits_top"], ts["virtual_merges_used"], ts["declined"], ts["gave_up"]))
 print("control ms: total %.1f | sifts %.1f (pops %d) merges %.1f top fetch %.1f result waits %.1f find epilogues %.1f (incl. their sift) | wavefront 1 selection %.1f" % (
     st["ctrl_ticks_100MHz"] / 1e5, ts["sift_ticks"] / 1e5, ts["pops"], ts["merge_ticks"] / 1e5, ts["top_fetch_ticks"] / 1e5, ts["wait_ticks_100MHz"] / 1e5,
     ts["epilogue_ticks"] / 1e5, ts["select_ticks"] / 1e5))
