@@ -636,16 +636,15 @@ static int pnnquan_rgb(nqo_quantizer* q, int nMaxColors, int32_t* palette) {
 /* ------------------------------------------------------------------------------------------------ */
 typedef struct { float ac, Lc, Ac, Bc, err, cnt; int nn, fw, bk, tm, mtm; int present; } PnnbinLAB;
 
-/* :44-115 */
-static void find_nn_lab(nqo_quantizer* q, PnnbinLAB* bins, int idx, int texicab) {
-    q->find_nn_calls++;
+/* :44-115.  The scan itself, without side effects: count n1 and means lab1 of the bin, the forward list from `start`, `skip` = a bin to be
+ * passed over as if it had been unlinked (-1: none; only the virtual-merge check below uses it). */
+static void find_nn_lab_core(const nqo_quantizer* q, const PnnbinLAB* bins, int start, float n1, Lab lab1, int skip, int texicab,
+                             double* err_out, int* nn_out) {
     int nn = 0;
     double err = 1e100;
-    PnnbinLAB* bin1 = &bins[idx];
-    float n1 = bin1->cnt;
     const double ratio = q->ratio;
-    Lab lab1; lab1.alpha = bin1->ac; lab1.L = bin1->Lc; lab1.A = bin1->Ac; lab1.B = bin1->Bc;
-    for (int i = bin1->fw; i != 0; i = bins[i].fw) {
+    for (int i = start; i != 0; i = bins[i].fw) {
+        if (i == skip) continue;
         float n2 = bins[i].cnt;
         double nerr2 = (n1 * n2) / (n1 + n2);
         if (nerr2 >= err) continue;
@@ -681,8 +680,25 @@ static void find_nn_lab(nqo_quantizer* q, PnnbinLAB* bins, int idx, int texicab)
         err = nerr;
         nn = i;
     }
+    *err_out = err; *nn_out = nn;
+}
+static void find_nn_lab(nqo_quantizer* q, PnnbinLAB* bins, int idx, int texicab) {
+    q->find_nn_calls++;
+    PnnbinLAB* bin1 = &bins[idx];
+    Lab lab1; lab1.alpha = bin1->ac; lab1.L = bin1->Lc; lab1.A = bin1->Ac; lab1.B = bin1->Bc;
+    double err; int nn;
+    find_nn_lab_core(q, bins, bin1->fw, bin1->cnt, lab1, -1, texicab, &err, &nn);
     bin1->err = (float) err;
     bin1->nn = nn;
+}
+/* Self-check of the premise behind the GPU's "virtual merge" (csrc/nq_merge.inc): the find_nn that follows the merge of a bin with its
+ * neighbour equals a scan made BEFORE that merge with the merged count and means and with the neighbour passed over.  When switched on,
+ * every merge of the LAB loop computes both and counts the merges and the differences (bit for bit: err as float, nn). */
+static int g_vm_check = 0;
+static int64_t g_vm_merges = 0, g_vm_diffs = 0;
+void nqo_debug_virtual_merge(int on, int64_t* out2) {
+    if (out2) { out2[0] = g_vm_merges; out2[1] = g_vm_diffs; }
+    g_vm_check = on; g_vm_merges = g_vm_diffs = 0;
 }
 
 static int pnnquan_lab(nqo_quantizer* q, int nMaxColors, int32_t* palette) {
@@ -830,6 +846,12 @@ static int pnnquan_lab(nqo_quantizer* q, int nMaxColors, int32_t* palette) {
         PnnbinLAB* nb = &bins[tb->nn];
         float n1 = tb->cnt, n2 = nb->cnt;
         float d = 1.0f / (n1 + n2);
+        double v_err = 0; int v_nn = 0;
+        if (g_vm_check) {      /* the scan as a helper of the GPU's merge team makes it: before the merge, on the unchanged lists */
+            Lab m; m.alpha = d * (n1 * tb->ac + n2 * nb->ac); m.L = d * (n1 * tb->Lc + n2 * nb->Lc);
+            m.A = d * (n1 * tb->Ac + n2 * nb->Ac); m.B = d * (n1 * tb->Bc + n2 * nb->Bc);
+            find_nn_lab_core(q, bins, tb->fw, n1 + n2, m, tb->nn, texicab, &v_err, &v_nn);
+        }
         tb->ac = d * (n1 * tb->ac + n2 * nb->ac);
         tb->Lc = d * (n1 * tb->Lc + n2 * nb->Lc);
         tb->Ac = d * (n1 * tb->Ac + n2 * nb->Ac);
@@ -839,6 +861,13 @@ static int pnnquan_lab(nqo_quantizer* q, int nMaxColors, int32_t* palette) {
         bins[nb->bk].fw = nb->fw;
         bins[nb->fw].bk = nb->bk;
         nb->mtm = 0xFFFF;
+        if (g_vm_check) {      /* ... and the scan the loop's next turn will make */
+            Lab m; m.alpha = tb->ac; m.L = tb->Lc; m.A = tb->Ac; m.B = tb->Bc;
+            double r_err; int r_nn;
+            find_nn_lab_core(q, bins, tb->fw, tb->cnt, m, -1, texicab, &r_err, &r_nn);
+            ++g_vm_merges;
+            if ((float) r_err != (float) v_err || r_nn != v_nn) ++g_vm_diffs;
+        }
     }
     q->t_stage[3] += now_s() - t0;
     /* :315-326 */

@@ -64,6 +64,8 @@ def lib():
     L.nqo_ciede2000.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.nqo_ciede_terms.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     L.nqo_ciede_terms.restype = None
+    L.nqo_debug_virtual_merge.argtypes = [C.c_int, C.c_void_p]
+    L.nqo_debug_virtual_merge.restype = None
     L.nqo_y_diff.restype = C.c_double
     L.nqo_y_diff.argtypes = [C.c_int32, C.c_int32]
     L.nqo_u_diff.restype = C.c_double
