@@ -465,19 +465,19 @@ static Lab getLab(nqo_quantizer* q, int32_t c) {
 /* ------------------------------------------------------------------------------------------------ */
 typedef struct { double ac, rc, gc, bc; float cnt, err; int nn, fw, bk, tm, mtm; int present; } PnnbinRGB;
 
-/* :57-116 */
-static void find_nn_rgb(nqo_quantizer* q, PnnbinRGB* bins, int idx) {
-    q->find_nn_calls++;
+/* :57-116.  The scan itself, without side effects: bin index idx (the blue-noise row choice), its count n1 and means w[4] = a, r, g, b, the
+ * forward list from `first`, `skip` = a bin to be passed over as if it had been unlinked (-1: none; the virtual-merge check only). */
+static void find_nn_rgb_core(const nqo_quantizer* q, const PnnbinRGB* bins, int idx, int first, float n1, const double* w, int skip,
+                             double* err_out, int* nn_out) {
     int nn = 0;
     double err = 1e100;
-    PnnbinRGB* bin1 = &bins[idx];
-    float n1 = bin1->cnt;
-    double wa = bin1->ac, wr = bin1->rc, wg = bin1->gc, wb = bin1->bc;
+    const double wa = w[0], wr = w[1], wg = w[2], wb = w[3];
     int start = 0;
     if (TELL_BLUE_NOISE[idx & 4095] > 0)
         start = (q->PG < coeffs[0][1]) ? 3 : 1;
     const double ratio = q->ratio, PR = q->PR, PG = q->PG, PB = q->PB, PA = q->PA;
-    for (int i = bin1->fw; i != 0; i = bins[i].fw) {
+    for (int i = first; i != 0; i = bins[i].fw) {
+        if (i == skip) continue;
         double n2 = bins[i].cnt, nerr2 = (n1 * n2) / (n1 + n2);
         if (nerr2 >= err) continue;
         double nerr = 0.0;
@@ -502,9 +502,20 @@ static void find_nn_rgb(nqo_quantizer* q, PnnbinRGB* bins, int idx) {
         err = nerr;           /* unconditional: reference quirk, SURVEY 8a row P7 */
         nn = i;
     }
+    *err_out = err; *nn_out = nn;
+}
+static void find_nn_rgb(nqo_quantizer* q, PnnbinRGB* bins, int idx) {
+    q->find_nn_calls++;
+    PnnbinRGB* bin1 = &bins[idx];
+    const double w[4] = {bin1->ac, bin1->rc, bin1->gc, bin1->bc};
+    double err; int nn;
+    find_nn_rgb_core(q, bins, idx, bin1->fw, bin1->cnt, w, -1, &err, &nn);
     bin1->err = (float) err;
     bin1->nn = nn;
 }
+/* (the switch and the counters of the virtual-merge self-check: defined with the LAB loop below) */
+static int g_vm_check;
+static int64_t g_vm_merges, g_vm_diffs;
 
 /* (int) Math.cbrt(cnt) for an integer-valued count.  The double result on perfect cubes is libm dependent (glibc returns
  * 14.999999999999998 for 3375.0; HotSpot runs fdlibm, ART runs bionic/msun), so the truncation is unpinned exactly there.
@@ -609,6 +620,12 @@ static int pnnquan_rgb(nqo_quantizer* q, int nMaxColors, int32_t* palette) {
         PnnbinRGB* nb = &bins[tb->nn];
         float n1 = tb->cnt, n2 = nb->cnt;
         float d = 1.0f / (n1 + n2);
+        double v_err = 0; int v_nn = 0;
+        if (g_vm_check) {      /* the scan before the merge: merged count and means, the neighbour passed over (see the LAB loop) */
+            const double m[4] = {d * (float) j_round(n1 * tb->ac + n2 * nb->ac), d * (float) j_round(n1 * tb->rc + n2 * nb->rc),
+                                 d * (float) j_round(n1 * tb->gc + n2 * nb->gc), d * (float) j_round(n1 * tb->bc + n2 * nb->bc)};
+            find_nn_rgb_core(q, bins, (int) (tb - bins), tb->fw, n1 + n2, m, tb->nn, &v_err, &v_nn);
+        }
         tb->ac = d * (float) j_round(n1 * tb->ac + n2 * nb->ac);   /* float * long -> float */
         tb->rc = d * (float) j_round(n1 * tb->rc + n2 * nb->rc);
         tb->gc = d * (float) j_round(n1 * tb->gc + n2 * nb->gc);
@@ -618,6 +635,13 @@ static int pnnquan_rgb(nqo_quantizer* q, int nMaxColors, int32_t* palette) {
         bins[nb->bk].fw = nb->fw;
         bins[nb->fw].bk = nb->bk;
         nb->mtm = 0xFFFF;
+        if (g_vm_check) {      /* ... and the scan the loop's next turn will make */
+            const double m[4] = {tb->ac, tb->rc, tb->gc, tb->bc};
+            double r_err; int r_nn;
+            find_nn_rgb_core(q, bins, (int) (tb - bins), tb->fw, tb->cnt, m, -1, &r_err, &r_nn);
+            ++g_vm_merges;
+            if ((float) r_err != (float) v_err || r_nn != v_nn) ++g_vm_diffs;
+        }
     }
     q->t_stage[3] += now_s() - t0;
     /* :258-266 */
@@ -693,9 +717,8 @@ static void find_nn_lab(nqo_quantizer* q, PnnbinLAB* bins, int idx, int texicab)
 }
 /* Self-check of the premise behind the GPU's "virtual merge" (csrc/nq_merge.inc): the find_nn that follows the merge of a bin with its
  * neighbour equals a scan made BEFORE that merge with the merged count and means and with the neighbour passed over.  When switched on,
- * every merge of the LAB loop computes both and counts the merges and the differences (bit for bit: err as float, nn). */
-static int g_vm_check = 0;
-static int64_t g_vm_merges = 0, g_vm_diffs = 0;
+ * every merge of the LAB loop (and of the RGB loop, for which the GPU has no virtual merge yet) computes both and counts the merges and the differences (bit for bit: err as float, nn). */
+/* (g_vm_check, g_vm_merges, g_vm_diffs: declared with the RGB loop above) */
 void nqo_debug_virtual_merge(int on, int64_t* out2) {
     if (out2) { out2[0] = g_vm_merges; out2[1] = g_vm_diffs; }
     g_vm_check = on; g_vm_merges = g_vm_diffs = 0;

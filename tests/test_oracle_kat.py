@@ -178,22 +178,24 @@ def test_integer_cube_root_resolution(oracle):
             assert int(lm.cbrt(float(v))) == exact, v
 
 
+@pytest.mark.parametrize("kind", [1, 0])
 @pytest.mark.parametrize("mk,K", [("gradient_noise", 256), ("uniform_rgb", 64), ("with_alpha", 256), ("few_colors", 16)])
-def test_virtual_merge_premise_holds_in_the_oracle(oracle, mk, K):
+def test_virtual_merge_premise_holds_in_the_oracle(oracle, mk, K, kind):
     """The GPU's merge teams compute the find_nn that FOLLOWS a merge before the merge happens (csrc/nq_merge.inc, "virtual merge"): a scan
     over the unchanged lists with the merged count and means (`d = 1f / (n1 + n2)`, `d * (n1 x1 + n2 x2)`, NQ/PnnLABQuantizer.java:297-306)
     and with the neighbour passed over.  The oracle checks that premise at every merge of its own LAB loop: both scans, err (as float) and
-    nn compared bit for bit -- texicab and non-texicab ladders, semi-transparency (the alpha term), few-hundred-bin images."""
+    nn compared bit for bit -- texicab and non-texicab ladders, semi-transparency (the alpha term), few-hundred-bin images.  kind 0: the same
+    premise for the RGB loop (`d * Math.round(n1 x1 + n2 x2)`, NQ/PnnQuantizer.java:240-248), which the GPU does not use yet."""
     from nquant.android_amd import synth
     img = {"gradient_noise": lambda: synth.gradient_noise(96, 80, 5), "uniform_rgb": lambda: synth.uniform_rgb(72, 72, 6),
            "with_alpha": lambda: synth.with_alpha(synth.gradient_noise(96, 96, 7), 7), "few_colors": lambda: synth.few_colors(96, 96, 8, 700)}[mk]()
     L = oracle.lib()
-    oq = oracle.OracleQuantizer(1, img, seed=1)
+    oq = oracle.OracleQuantizer(kind, img, seed=1)
     oq.prescan(K)
     plain = oq.pnnquan(K)
     L.nqo_debug_virtual_merge(1, None)
     try:
-        oq2 = oracle.OracleQuantizer(1, img, seed=1)
+        oq2 = oracle.OracleQuantizer(kind, img, seed=1)
         oq2.prescan(K)
         checked = oq2.pnnquan(K)
     finally:
